@@ -1,0 +1,194 @@
+/*
+ * ssw_amd.h -- C ABI of the MI355X-native SoundSwallower acoustic hot path.
+ *
+ * Everything here is `extern "C"`, plain pointers and sizes.  Each entry point names the
+ * reference interface it stands in for (file:line relative to the SoundSwallower tree) so a
+ * maintainer can bind it from the reference's C code; INTEGRATION.md shows the binding.
+ *
+ * Conventions follow the reference: int return, 0 on success, < 0 on error (the message is
+ * kept per thread and returned by ssw_last_error()); constructors return NULL on error;
+ * objects are freed by their *_free function.  Calls are synchronous unless a stream is passed.
+ * Pointers named d_* are device (HIP) pointers, everything else is host memory.
+ */
+#ifndef SSW_AMD_H
+#define SSW_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSW_ABI_VERSION 1
+
+/* ------------------------------------------------------------------------------------ */
+/* Configuration: the scalar parameters the path reads from config_t                     */
+/* (include/soundswallower/config_defs.h:94-97, 198-253).                                */
+/* ------------------------------------------------------------------------------------ */
+typedef struct ssw_config_s {
+    double logbase;   /* "logbase"   1.0001 */
+    double varfloor;  /* "varfloor"  1e-4   */
+    double mixwfloor; /* "mixwfloor" 1e-7   */
+    double tmatfloor; /* "tmatfloor" 1e-4   */
+    int32_t topn;     /* "topn"      4      */
+    int32_t ds;       /* "ds"        1      */
+    int32_t aw;       /* "aw"        1      */
+    int32_t device;   /* HIP device ordinal; -1 = current device */
+} ssw_config_t;
+
+void ssw_config_defaults(ssw_config_t *cfg);
+const char *ssw_last_error(void);
+int ssw_abi_version(void);
+
+/* ------------------------------------------------------------------------------------ */
+/* Acoustic model: replaces the loading half of acmod_load_am (src/acmod.c:62-129):      */
+/* bin_mdef_read (src/bin_mdef.c:310), tmat_init (src/tmat.c:107), gauden_init           */
+/* (src/ms_gauden.c:304), read_sendump / read_mixw (src/ptm_mgau.c:456, 611),            */
+/* senone_mixw_read (src/ms_senone.c:103).  Tables are derived on the host exactly as    */
+/* the reference derives them, then laid out for the GPU and uploaded once.              */
+/* ------------------------------------------------------------------------------------ */
+typedef struct ssw_model_s ssw_model_t;
+
+/* sendump or mixw may be NULL (one of them is required for scoring); mdef/tmat may be NULL
+ * when only scoring tables are wanted and n_sen can be taken from mixw. */
+ssw_model_t *ssw_model_load(const char *mdef, const char *means, const char *variances,
+                            const char *sendump, const char *mixw, const char *tmat,
+                            const ssw_config_t *cfg);
+void ssw_model_free(ssw_model_t *m);
+
+typedef struct ssw_model_info_s {
+    int32_t n_cb, n_feat, n_density, veclen_total;
+    int32_t n_sen, n_ci_sen, n_ciphone, n_phone, n_emit_state, n_tmat, n_sseq, sil;
+    int32_t n_floored, topn, has_ptm, has_ms, device;
+    int32_t veclen[8];
+} ssw_model_info_t;
+int ssw_model_info(const ssw_model_t *m, ssw_model_info_t *out);
+
+/* Host copies of the derived tables, for loader parity checks.  Returns a pointer owned by
+ * the model and writes the byte size.  Layouts: MEAN/VAR float32 in s3 file order
+ * [cb][feat][density][veclen]; DET float32 [cb][feat][density]; PTM_MIXW uint8
+ * [feat][density][n_sen]; MS_PDF uint8 [sen][feat][density]; TP uint8 [tmat][n][n+1];
+ * SSEQ uint16 [n_sseq][n_emit]; SEN2CB int16 [n_sen]; LOGADD8 uint8[256];
+ * PHONE_SSID / PHONE_TMAT int32 [n_phone]. */
+enum ssw_table {
+    SSW_TAB_MEAN = 0, SSW_TAB_VAR, SSW_TAB_DET, SSW_TAB_PTM_MIXW, SSW_TAB_MS_PDF, SSW_TAB_TP,
+    SSW_TAB_SSEQ, SSW_TAB_SEN2CB, SSW_TAB_LOGADD8, SSW_TAB_PHONE_SSID, SSW_TAB_PHONE_TMAT
+};
+const void *ssw_model_table(const ssw_model_t *m, int which, size_t *nbytes);
+
+/* ------------------------------------------------------------------------------------ */
+/* Batched senone scoring (NEW: the reference scores one frame per call).                */
+/* One call scores every frame of a batch of utterances with compallsen = yes:           */
+/*   acmod_score -> ptm_mgau_frame_eval   (src/acmod.c:822-860, src/ptm_mgau.c:408-454)   */
+/*   acmod_score -> ms_cont_mgau_frame_eval (src/ms_mgau.c:278-368)                       */
+/* feats: float32 [n_frames][veclen_total] (streams back to back, the row acmod keeps in  */
+/* feat_buf, src/feat.c:386-395).  utt_off: int32 [n_utts+1], frame offsets; every         */
+/* utterance starts from the reset top-N history {cw = m, score = INT32_MIN}              */
+/* (src/ptm_mgau.c:706-713).  out: int16 [n_frames][n_sen].                               */
+/* ------------------------------------------------------------------------------------ */
+enum ssw_scorer { SSW_SCORER_PTM = 0, SSW_SCORER_MS = 1 };
+
+/* device pointers, asynchronous on `stream` (a hipStream_t, NULL = default stream) */
+int ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_frames,
+                    const int32_t *utt_off, int32_t n_utts, int16_t *d_out, void *stream);
+/* host pointers, synchronous: copies in, scores, copies out */
+int ssw_score_batch_host(ssw_model_t *m, int scorer, const float *feats, int32_t n_frames,
+                         const int32_t *utt_off, int32_t n_utts, int16_t *out);
+/* Debug/parity view of the PTM top-N state after normalisation for every frame of the last
+ * ssw_score_batch* call: cw uint8 / score int32 laid out [n_frames][n_cb][n_feat][topn]. */
+int ssw_score_batch_topn(ssw_model_t *m, int32_t n_frames, uint8_t *cw, int32_t *score);
+/* Counters of the last PTM batch: [0] = (chain,frame) pairs the history-free pass could not
+ * prove order-independent and handed to the exact sequential pass, [1] = pairs total. */
+int ssw_score_batch_stats(ssw_model_t *m, int64_t stats[2]);
+
+/* ------------------------------------------------------------------------------------ */
+/* Scorer object: drop-in for mgau_t / mgaufuncs_t (include/soundswallower/acmod.h:93-111).*/
+/* The first two members mirror mgau_t so acmod can write frame_idx                       */
+/* (src/acmod.c:367,748,760) and call through vt.                                         */
+/* ------------------------------------------------------------------------------------ */
+typedef struct ssw_mgau_s ssw_mgau_t;
+typedef struct ssw_mgaufuncs_s {
+    const char *name;
+    int (*frame_eval)(ssw_mgau_t *mgau, int16_t *senscr, uint8_t *senone_active,
+                      int32_t n_senone_active, float **feat, int32_t frame,
+                      int32_t compallsen);
+    int (*transform)(ssw_mgau_t *mgau, void *mllr); /* MLLR is out of scope: returns -1 */
+    void (*free)(ssw_mgau_t *mgau);
+} ssw_mgaufuncs_t;
+struct ssw_mgau_s {
+    ssw_mgaufuncs_t *vt;
+    int frame_idx;
+};
+
+/* ptm_mgau_init(acmod_t *) (ptm_mgau.h:94) / ms_mgau_init(acmod_t *) (ms_mgau.h) */
+ssw_mgau_t *ssw_ptm_mgau_init(ssw_model_t *m);
+ssw_mgau_t *ssw_ms_mgau_init(ssw_model_t *m);
+/* ptm_mgau_reset_fast_hist (src/ptm_mgau.c:694) without its reallocation */
+void ssw_mgau_reset_hist(ssw_mgau_t *mgau);
+/* NEW: score a whole utterance in one batch and cache it; frame_eval(frame) then copies row
+ * `frame`.  Without it frame_eval scores one frame per call on the GPU. */
+int ssw_mgau_prescore(ssw_mgau_t *mgau, const float *feats, int32_t n_frames);
+
+/* ------------------------------------------------------------------------------------ */
+/* Forced alignment: state_align_search (src/state_align_search.c) + hmm_vit_eval         */
+/* (src/hmm.c:741) + the state level of alignment_t (include/soundswallower/alignment.h). */
+/* ------------------------------------------------------------------------------------ */
+typedef struct ssw_align_entry_s {
+    int32_t start, duration, score; /* alignment_entry_t.{start,duration,score} */
+} ssw_align_entry_t;
+
+/* Batch of independent utterances.
+ *   d_senscr  int16 [total_frames][n_sen]   scores as acmod_score returns them
+ *   frame_off int32 [n_utts+1]              rows of d_senscr per utterance
+ *   phone_off int32 [n_utts+1]              phones per utterance (offsets into per-phone arrays)
+ *   senid     uint16 [total_phones][n_emit] mdef->sseq[ssid][j] (src/hmm.c:99)
+ *   tmatid    int16 [total_phones]
+ *   sf, ef    int32 [total_phones]          state_align_search.c:464-471 (0 / INT_MAX = free)
+ *   state_io  [total_phones*n_emit]         in: what alignment_populate left in the state
+ *                                           entries (src/ps_alignment.c:237-239); out: backtrace
+ *   status    int32 [n_utts]                0 ok, -1 "Failed to reach final state",
+ *                                           -(2+frame) "Alignment failed in frame"
+ * All host pointers except d_senscr.  Synchronous. */
+int ssw_align_batch(ssw_model_t *m, const int16_t *d_senscr, int32_t n_utts,
+                    const int32_t *frame_off, const int32_t *phone_off, const uint16_t *senid,
+                    const int16_t *tmatid, const int32_t *sf, const int32_t *ef,
+                    ssw_align_entry_t *state_io, int32_t *status, void *stream);
+/* alignment_propagate (src/ps_alignment.c:316-352): sums children into parents.
+ * parent[i] = index of child i's parent; parents must appear in non-decreasing order. */
+int ssw_alignment_propagate(const ssw_align_entry_t *child, const int32_t *parent,
+                            int32_t n_child, ssw_align_entry_t *parent_out, int32_t n_parent);
+
+/* Search-module shaped object: state_align_search_init/start/step/finish/free
+ * (state_align_search.h:89-92; vtable slots of search_module.h:72-83).  The constructor takes
+ * what state_align_search_init reads from the alignment's phone level
+ * (src/state_align_search.c:458-471): per phone ssid, tmatid, start, duration. */
+typedef struct ssw_state_align_search_s ssw_state_align_search_t;
+ssw_state_align_search_t *ssw_state_align_search_init(ssw_model_t *m, ssw_mgau_t *mgau,
+                                                      int32_t n_phones, const int32_t *ssid,
+                                                      const int32_t *tmatid,
+                                                      const int32_t *start,
+                                                      const int32_t *duration);
+int ssw_state_align_search_start(ssw_state_align_search_t *s);
+/* feat = the frame's feature row; frames must be stepped in order from 0 */
+int ssw_state_align_search_step(ssw_state_align_search_t *s, const float *feat, int frame_idx);
+/* runs scoring + Viterbi + backtrace for all stepped frames; fills state/phone entries */
+int ssw_state_align_search_finish(ssw_state_align_search_t *s);
+int32_t ssw_state_align_search_n_frames(const ssw_state_align_search_t *s);
+const ssw_align_entry_t *ssw_state_align_search_states(const ssw_state_align_search_t *s,
+                                                       int32_t *n);
+const ssw_align_entry_t *ssw_state_align_search_phones(const ssw_state_align_search_t *s,
+                                                       int32_t *n);
+void ssw_state_align_search_free(ssw_state_align_search_t *s);
+
+/* device-memory helpers so a C caller needs no HIP headers */
+void *ssw_device_malloc(size_t nbytes);
+void ssw_device_free(void *d_ptr);
+int ssw_memcpy_h2d(void *d_dst, const void *src, size_t nbytes);
+int ssw_memcpy_d2h(void *dst, const void *d_src, size_t nbytes);
+int ssw_device_synchronize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSW_AMD_H */

@@ -1,0 +1,11 @@
+"""MI355X-native SoundSwallower acoustic hot path: GMM senone scoring + forced alignment.
+
+The compute lives in `libssw_amd.so` (C host code + hand-written gfx950 HIP kernels) behind the
+C ABI of `include/ssw_amd.h`; this package is the thin host mirror used by tests and bench.
+"""
+from .api import (INT_MAX, SCORER_MS, SCORER_PTM, Model, PtmMgau, StateAlignSearch, SswError,
+                  model_dir)
+from .synth import lcg_uniform, synth_features, synth_alignment_task
+
+__all__ = ["Model", "PtmMgau", "StateAlignSearch", "SswError", "model_dir", "SCORER_PTM",
+           "SCORER_MS", "INT_MAX", "lcg_uniform", "synth_features", "synth_alignment_task"]

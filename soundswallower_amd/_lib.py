@@ -1,0 +1,118 @@
+"""Loader for the C-ABI shared library (soundswallower_amd/libssw_amd.so).
+
+The library is the product: HIP kernels for gfx950 plus the C host code.  There is no CPU
+fallback -- a missing library or a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssw_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "ssw_amd.h")
+
+_lib = None
+
+
+class SswConfig(C.Structure):
+    _fields_ = [("logbase", C.c_double), ("varfloor", C.c_double), ("mixwfloor", C.c_double),
+                ("tmatfloor", C.c_double), ("topn", C.c_int32), ("ds", C.c_int32),
+                ("aw", C.c_int32), ("device", C.c_int32)]
+
+
+class SswModelInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("n_cb", "n_feat", "n_density", "veclen_total", "n_sen", "n_ci_sen", "n_ciphone",
+                 "n_phone", "n_emit_state", "n_tmat", "n_sseq", "sil", "n_floored", "topn",
+                 "has_ptm", "has_ms", "device")] + [("veclen", C.c_int32 * 8)]
+
+
+class SswAlignEntry(C.Structure):
+    _fields_ = [("start", C.c_int32), ("duration", C.c_int32), ("score", C.c_int32)]
+
+
+FRAME_EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                            C.POINTER(C.POINTER(C.c_float)), C.c_int32, C.c_int32)
+TRANSFORM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+FREE_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class SswMgauFuncs(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("frame_eval", FRAME_EVAL_FN), ("transform", TRANSFORM_FN),
+                ("free", FREE_FN)]
+
+
+class SswMgau(C.Structure):
+    _fields_ = [("vt", C.POINTER(SswMgauFuncs)), ("frame_idx", C.c_int)]
+
+
+def build(force: bool = False) -> str:
+    """Compile libssw_amd.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
+            if f.endswith((".c", ".hip", ".h"))] + [HEADER]
+    stale = (not os.path.exists(LIB_PATH)
+             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))
+    if force or stale:
+        args = ["make", "-C", CSRC] + (["-B"] if force else [])
+        subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """The loaded C-ABI library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with __graft_entry__.build() or "
+            f"`make -C {CSRC}`; soundswallower_amd has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
+    L.ssw_config_defaults.argtypes = [C.POINTER(SswConfig)]
+    L.ssw_last_error.restype = C.c_char_p
+    L.ssw_abi_version.restype = C.c_int
+    L.ssw_model_load.restype = vp
+    L.ssw_model_load.argtypes = [C.c_char_p] * 6 + [C.POINTER(SswConfig)]
+    L.ssw_model_free.argtypes = [vp]
+    L.ssw_model_info.argtypes = [vp, C.POINTER(SswModelInfo)]
+    L.ssw_model_table.restype = vp
+    L.ssw_model_table.argtypes = [vp, C.c_int, C.POINTER(sz)]
+    L.ssw_score_batch.argtypes = [vp, C.c_int, vp, i32, vp, i32, vp, vp]
+    L.ssw_score_batch_host.argtypes = [vp, C.c_int, vp, i32, vp, i32, vp]
+    L.ssw_score_batch_topn.argtypes = [vp, i32, vp, vp]
+    L.ssw_score_batch_stats.argtypes = [vp, vp]
+    L.ssw_ptm_mgau_init.restype = C.POINTER(SswMgau)
+    L.ssw_ptm_mgau_init.argtypes = [vp]
+    L.ssw_ms_mgau_init.restype = C.POINTER(SswMgau)
+    L.ssw_ms_mgau_init.argtypes = [vp]
+    L.ssw_mgau_reset_hist.argtypes = [C.POINTER(SswMgau)]
+    L.ssw_mgau_prescore.argtypes = [C.POINTER(SswMgau), vp, i32]
+    L.ssw_align_batch.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ssw_alignment_propagate.argtypes = [vp, vp, i32, vp, i32]
+    L.ssw_state_align_search_init.restype = vp
+    L.ssw_state_align_search_init.argtypes = [vp, C.POINTER(SswMgau), i32, vp, vp, vp, vp]
+    L.ssw_state_align_search_start.argtypes = [vp]
+    L.ssw_state_align_search_step.argtypes = [vp, vp, C.c_int]
+    L.ssw_state_align_search_finish.argtypes = [vp]
+    L.ssw_state_align_search_n_frames.restype = i32
+    L.ssw_state_align_search_n_frames.argtypes = [vp]
+    L.ssw_state_align_search_states.restype = C.POINTER(SswAlignEntry)
+    L.ssw_state_align_search_states.argtypes = [vp, C.POINTER(i32)]
+    L.ssw_state_align_search_phones.restype = C.POINTER(SswAlignEntry)
+    L.ssw_state_align_search_phones.argtypes = [vp, C.POINTER(i32)]
+    L.ssw_state_align_search_free.argtypes = [vp]
+    L.ssw_device_malloc.restype = vp
+    L.ssw_device_malloc.argtypes = [sz]
+    L.ssw_device_free.argtypes = [vp]
+    L.ssw_memcpy_h2d.argtypes = [vp, vp, sz]
+    L.ssw_memcpy_d2h.argtypes = [vp, vp, sz]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().ssw_last_error().decode(errors="replace")

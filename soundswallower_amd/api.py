@@ -1,0 +1,287 @@
+"""Host-side mirror of the reference's interfaces for the accelerated path, over the C ABI.
+
+Names follow the reference: `Model` stands for what `acmod_load_am` loads, `PtmMgau` for the
+`mgau_t` returned by `ptm_mgau_init` (its `frame_eval` is the vtable slot `acmod_score`
+calls), `StateAlignSearch` for `state_align_search_init/start/step/finish`.  Everything runs on
+the GPU through `libssw_amd.so`; there is no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import SswAlignEntry, SswConfig, SswModelInfo
+
+SCORER_PTM = 0
+SCORER_MS = 1
+INT_MAX = 2**31 - 1
+
+_TABLES = {
+    "mean": (0, np.float32), "var": (1, np.float32), "det": (2, np.float32),
+    "ptm_mixw": (3, np.uint8), "ms_pdf": (4, np.uint8), "tp": (5, np.uint8),
+    "sseq": (6, np.uint16), "sen2cb": (7, np.int16), "logadd8": (8, np.uint8),
+    "phone_ssid": (9, np.int32), "phone_tmat": (10, np.int32),
+}
+
+
+class SswError(RuntimeError):
+    pass
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if hasattr(a, "data_ptr"):  # torch tensor
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(int(a))
+
+
+def _check(rv, what):
+    if rv is None or (isinstance(rv, int) and rv < 0):
+        raise SswError(f"{what}: {_lib.last_error()}")
+    return rv
+
+
+def model_dir(name: str) -> str:
+    """Path of a bundled acoustic model ("en-us", "fr-fr")."""
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "model", name)
+
+
+class Model:
+    """Acoustic model tables on the GPU (ssw_model_load)."""
+
+    def __init__(self, path=None, *, mdef=None, means=None, variances=None, sendump=None,
+                 mixw=None, tmat=None, config=None):
+        L = _lib.lib()
+        if path is not None:
+            j = lambda n: os.path.join(path, n)
+            mdef = mdef or j("mdef")
+            means = means or j("means")
+            variances = variances or j("variances")
+            tmat = tmat or j("transition_matrices")
+            if sendump is None and mixw is None:
+                if os.path.exists(j("sendump")):
+                    sendump = j("sendump")
+                else:
+                    mixw = j("mixture_weights")
+        cfg = SswConfig()
+        L.ssw_config_defaults(C.byref(cfg))
+        for k, v in (config or {}).items():
+            setattr(cfg, k, v)
+        enc = lambda s: None if s is None else os.fsencode(s)
+        self._L = L
+        self._m = L.ssw_model_load(enc(mdef), enc(means), enc(variances), enc(sendump),
+                                   enc(mixw), enc(tmat), C.byref(cfg))
+        if not self._m:
+            raise SswError("ssw_model_load: " + _lib.last_error())
+        info = SswModelInfo()
+        L.ssw_model_info(self._m, C.byref(info))
+        self.info = info
+        for name, _ in SswModelInfo._fields_:
+            if name != "veclen":
+                setattr(self, name, int(getattr(info, name)))
+        self.veclen = [int(info.veclen[i]) for i in range(self.n_feat)]
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self._L.ssw_model_free(self._m)
+            self._m = None
+
+    __del__ = close
+
+    def table(self, name: str) -> np.ndarray:
+        """Host copy of a derived table (flat), for loader parity checks."""
+        which, dtype = _TABLES[name]
+        n = C.c_size_t(0)
+        p = self._L.ssw_model_table(self._m, which, C.byref(n))
+        if not p or n.value == 0:
+            return np.zeros(0, dtype)
+        buf = (C.c_char * n.value).from_address(p)
+        return np.frombuffer(buf, dtype=dtype).copy()
+
+    # ---- scoring ------------------------------------------------------------------
+    def score_batch(self, feats, utt_off=None, scorer=SCORER_PTM) -> np.ndarray:
+        """Score host features [n_frames][39]; returns int16 [n_frames][n_sen]."""
+        feats = np.ascontiguousarray(feats, dtype=np.float32).reshape(-1, self.veclen_total)
+        n = feats.shape[0]
+        off = (np.array([0, n], np.int32) if utt_off is None
+               else np.ascontiguousarray(utt_off, np.int32))
+        out = np.zeros((n, self.n_sen), np.int16)
+        _check(self._L.ssw_score_batch_host(self._m, scorer, _ptr(feats), n, _ptr(off),
+                                            len(off) - 1, _ptr(out)), "ssw_score_batch_host")
+        return out
+
+    def score_batch_device(self, d_feats, n_frames, utt_off, d_out, stream=None,
+                           scorer=SCORER_PTM):
+        """Device pointers (ints or torch tensors); asynchronous on `stream`."""
+        off = np.ascontiguousarray(utt_off, np.int32)
+        _check(self._L.ssw_score_batch(self._m, scorer, _ptr(d_feats), int(n_frames), _ptr(off),
+                                       len(off) - 1, _ptr(d_out),
+                                       C.c_void_p(int(stream)) if stream else None),
+               "ssw_score_batch")
+
+    def last_topn(self, n_frames):
+        n_cbf = self.n_cb * self.n_feat
+        cw = np.zeros((n_frames, self.n_cb, self.n_feat, self.topn), np.uint8)
+        sc = np.zeros((n_frames, self.n_cb, self.n_feat, self.topn), np.int32)
+        _check(self._L.ssw_score_batch_topn(self._m, n_frames, _ptr(cw), _ptr(sc)),
+               "ssw_score_batch_topn")
+        assert cw.size == n_frames * n_cbf * self.topn
+        return cw, sc
+
+    def last_stats(self):
+        st = np.zeros(2, np.int64)
+        self._L.ssw_score_batch_stats(self._m, _ptr(st))
+        return int(st[0]), int(st[1])
+
+    # ---- alignment ----------------------------------------------------------------
+    def align_batch(self, d_senscr, frame_off, phone_off, senid, tmatid, sf=None, ef=None,
+                    state_init=None, stream=None):
+        """Viterbi forced alignment of a batch; returns (states[n,3] int32, status[n_utts])."""
+        frame_off = np.ascontiguousarray(frame_off, np.int32)
+        phone_off = np.ascontiguousarray(phone_off, np.int32)
+        senid = np.ascontiguousarray(senid, np.uint16).reshape(-1, 3)
+        n_ph = senid.shape[0]
+        tmatid = np.ascontiguousarray(tmatid, np.int16)
+        sf = np.zeros(n_ph, np.int32) if sf is None else np.ascontiguousarray(sf, np.int32)
+        ef = (np.full(n_ph, INT_MAX, np.int32) if ef is None
+              else np.ascontiguousarray(ef, np.int32))
+        states = (np.zeros((n_ph * 3, 3), np.int32) if state_init is None
+                  else np.ascontiguousarray(state_init, np.int32).copy())
+        n_utts = len(frame_off) - 1
+        status = np.zeros(n_utts, np.int32)
+        _check(self._L.ssw_align_batch(self._m, _ptr(d_senscr), n_utts, _ptr(frame_off),
+                                       _ptr(phone_off), _ptr(senid), _ptr(tmatid), _ptr(sf),
+                                       _ptr(ef), _ptr(states), _ptr(status),
+                                       C.c_void_p(int(stream)) if stream else None),
+               "ssw_align_batch")
+        return states, status
+
+    def propagate(self, child, parent, n_parent):
+        child = np.ascontiguousarray(child, np.int32)
+        parent = np.ascontiguousarray(parent, np.int32)
+        out = np.zeros((n_parent, 3), np.int32)
+        _check(self._L.ssw_alignment_propagate(_ptr(child), _ptr(parent), len(parent), _ptr(out),
+                                               n_parent), "ssw_alignment_propagate")
+        return out
+
+    # ---- device memory (no torch needed) --------------------------------------------
+    def to_device(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        p = _check(self._L.ssw_device_malloc(arr.nbytes), "ssw_device_malloc")
+        _check(self._L.ssw_memcpy_h2d(p, _ptr(arr), arr.nbytes), "ssw_memcpy_h2d")
+        return p
+
+    def device_free(self, p):
+        self._L.ssw_device_free(p)
+
+
+class PtmMgau:
+    """`mgau_t` stand-in created by ssw_ptm_mgau_init; call through its vtable."""
+
+    def __init__(self, model: Model):
+        self._L = _lib.lib()
+        self.model = model
+        self._g = self._L.ssw_ptm_mgau_init(model._m)
+        if not self._g:
+            raise SswError("ssw_ptm_mgau_init: " + _lib.last_error())
+
+    @property
+    def name(self):
+        return self._g.contents.vt.contents.name.decode()
+
+    @property
+    def frame_idx(self):
+        return self._g.contents.frame_idx
+
+    @frame_idx.setter
+    def frame_idx(self, v):
+        self._g.contents.frame_idx = int(v)  # acmod writes this field directly
+
+    def reset_hist(self):
+        self._L.ssw_mgau_reset_hist(self._g)
+
+    def prescore(self, feats):
+        feats = np.ascontiguousarray(feats, np.float32).reshape(-1, self.model.veclen_total)
+        _check(self._L.ssw_mgau_prescore(self._g, _ptr(feats), feats.shape[0]),
+               "ssw_mgau_prescore")
+
+    def frame_eval(self, feat, frame, compallsen=True, senone_active=None):
+        m = self.model
+        feat = np.ascontiguousarray(feat, np.float32).reshape(-1)
+        streams = (C.POINTER(C.c_float) * m.n_feat)()
+        off = 0
+        for f in range(m.n_feat):
+            streams[f] = C.cast(feat[off:].ctypes.data, C.POINTER(C.c_float))
+            off += m.veclen[f]
+        out = np.zeros(m.n_sen, np.int16)
+        act = None if senone_active is None else np.ascontiguousarray(senone_active, np.uint8)
+        rv = self._g.contents.vt.contents.frame_eval(
+            C.cast(self._g, C.c_void_p), _ptr(out), _ptr(act),
+            0 if act is None else len(act), streams, int(frame), int(bool(compallsen)))
+        _check(rv, "frame_eval")
+        return out
+
+    def transform(self, mllr=None):
+        return self._g.contents.vt.contents.transform(C.cast(self._g, C.c_void_p), None)
+
+    def free(self):
+        if getattr(self, "_g", None):
+            self._g.contents.vt.contents.free(C.cast(self._g, C.c_void_p))
+            self._g = None
+
+    __del__ = free
+
+
+class StateAlignSearch:
+    """state_align_search_init/start/step/finish over one utterance."""
+
+    def __init__(self, model: Model, mgau: PtmMgau | None, ssid, tmatid, start=None,
+                 duration=None):
+        self._L = _lib.lib()
+        self.model = model
+        ssid = np.ascontiguousarray(ssid, np.int32)
+        tmatid = np.ascontiguousarray(tmatid, np.int32)
+        n = len(ssid)
+        start = None if start is None else np.ascontiguousarray(start, np.int32)
+        duration = None if duration is None else np.ascontiguousarray(duration, np.int32)
+        self._s = self._L.ssw_state_align_search_init(
+            model._m, mgau._g if mgau is not None else None, n, _ptr(ssid), _ptr(tmatid),
+            _ptr(start), _ptr(duration))
+        if not self._s:
+            raise SswError("ssw_state_align_search_init: " + _lib.last_error())
+
+    def start(self):
+        return _check(self._L.ssw_state_align_search_start(self._s), "start")
+
+    def step(self, feat, frame_idx):
+        feat = np.ascontiguousarray(feat, np.float32).reshape(-1)
+        return _check(self._L.ssw_state_align_search_step(self._s, _ptr(feat), int(frame_idx)),
+                      "step")
+
+    def finish(self):
+        return _check(self._L.ssw_state_align_search_finish(self._s), "finish")
+
+    def _entries(self, fn):
+        n = C.c_int32(0)
+        p = fn(self._s, C.byref(n))
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), shape=(n.value, 3))
+        return a.copy()
+
+    def states(self):
+        return self._entries(self._L.ssw_state_align_search_states)
+
+    def phones(self):
+        return self._entries(self._L.ssw_state_align_search_phones)
+
+    def free(self):
+        if getattr(self, "_s", None):
+            self._L.ssw_state_align_search_free(self._s)
+            self._s = None
+
+    __del__ = free

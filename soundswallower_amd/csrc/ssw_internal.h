@@ -1,0 +1,59 @@
+/* ssw_internal.h -- shared between the host C loaders and the HIP translation unit. */
+#ifndef SSW_INTERNAL_H
+#define SSW_INTERNAL_H
+
+#include "ssw_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSW_SENSCR_SHIFT 10
+#define SSW_WORST_SCORE ((int32_t)0xE0000000)
+#define SSW_MAX_NEG_ASCR 96
+#define SSW_MAX_NEG_MIXW 159
+#define SSW_MAX_FEAT 8
+
+/* Gaussian record on the device: one density = 32 floats = one 128-byte line.
+ *   [0 .. veclen)  mean      [15] det      [16 .. 16+veclen)  precomputed 1/(2 var) scale
+ * Unused slots are 0.0f, which makes a padded dimension an exact no-op (d - 0*0*0 = d). */
+#define SSW_REC_FLOATS 32
+#define SSW_REC_DET 15
+#define SSW_REC_VAR 16
+#define SSW_MAX_VECLEN 15
+
+/* Host-side model: every table derived exactly as the reference derives it. */
+typedef struct ssw_host_model_s {
+    ssw_config_t cfg;
+    /* Gaussians (gauden_t) */
+    int32_t n_cb, n_feat, n_density, veclen_total, n_floored;
+    int32_t veclen[SSW_MAX_FEAT], featoff[SSW_MAX_FEAT];
+    float *mean, *var, *det; /* file order / [cb][feat][density] */
+    /* mdef */
+    int32_t n_ciphone, n_phone, n_emit_state, n_ci_sen, n_sen, n_tmat, n_sseq, sil;
+    uint16_t *sseq;
+    int16_t *sen2cb; /* bin_mdef sen2cimap */
+    int32_t *phone_ssid, *phone_tmat;
+    /* tmat */
+    uint8_t *tp;
+    int32_t tp_n_tmat, tp_n_state;
+    /* mixture weights */
+    uint8_t *ptm_mixw; /* [feat][density][n_sen], 8-bit (4-bit clustered dumps are expanded) */
+    uint8_t *ms_pdf;   /* [sen][feat][density] */
+    /* log-add tables */
+    uint8_t logadd8[256];
+    int32_t logadd8_size;   /* entries produced by logmath_init (>= 256) */
+    int32_t zero8;          /* logmath zero at shift 10 */
+} ssw_host_model_t;
+
+ssw_host_model_t *ssw_host_model_load(const char *mdef, const char *means,
+                                      const char *variances, const char *sendump,
+                                      const char *mixw, const char *tmat,
+                                      const ssw_config_t *cfg);
+void ssw_host_model_free(ssw_host_model_t *h);
+void ssw_set_error(const char *fmt, ...);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1656 @@
+/*
+ * ssw_kernels.hip -- gfx950 (MI355X, CDNA4) kernels for the SoundSwallower acoustic hot path
+ * and the C ABI of include/ssw_amd.h on top of them.
+ *
+ * All arithmetic that the reference does in float32 is done here in float32 with one rounding
+ * per operation (no FMA contraction: this file is built with -ffp-contract=off and carries the
+ * pragma below), in the reference's operation order; everything else is int32.  Citations are
+ * file:line in the SoundSwallower tree.
+ *
+ * Kernels
+ *   ptm_topn_chain_kernel   exact frame-sequential top-N (eval_topn + eval_cb,
+ *                           src/ptm_mgau.c:86-225): one wave64 per (utterance, codebook,
+ *                           stream) chain, two densities per lane held in registers
+ *   ptm_senone_kernel       codebook_norm + senone_eval (src/ptm_mgau.c:264-403): one
+ *                           workgroup per frame, top-N block + log-add table in LDS
+ *   viterbi_align_kernel    state_align_search step/finish + hmm_vit_eval_3st_lr
+ *                           (src/state_align_search.c:177-268, src/hmm.c:482-567): one wave64
+ *                           per utterance, HMM state in LDS
+ */
+#pragma clang fp contract(off)
+
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ssw_internal.h"
+
+#define HIP_OK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ssw_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,   \
+                          __LINE__);                                                         \
+            return -1;                                                                       \
+        }                                                                                    \
+    } while (0)
+
+namespace {
+
+constexpr int WAVE = 64;
+
+/* ---------------------------------------------------------------------------------- */
+/* small device helpers                                                                */
+/* ---------------------------------------------------------------------------------- */
+
+/* (int32)d with the reference's clamp (src/ptm_mgau.c:128-131).  v_cvt_i32_f32 saturates, so
+ * the explicit compare only documents intent. */
+__device__ __forceinline__ int
+dens2int(float d)
+{
+    return d < -2147483648.0f ? INT_MIN : (int)d;
+}
+
+/* d = det - sum_j (x_j - mu_j)^2 v_j: sub, mul, mul, sub, each rounded, j ascending
+ * (src/ptm_mgau.c:63-68, src/ms_gauden.c:410-416). */
+template <int VECLEN>
+__device__ __forceinline__ float
+density(const float (&x)[VECLEN], const float (&mean)[VECLEN], const float (&var)[VECLEN],
+        float det)
+{
+    float d = det;
+#pragma unroll
+    for (int j = 0; j < VECLEN; ++j) {
+        float diff = x[j] - mean[j];
+        float sq = diff * diff;
+        float c = sq * var[j];
+        d = d - c;
+    }
+    return d;
+}
+
+__device__ __forceinline__ int
+wave_max_i32(int v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        int o = __shfl_xor(v, off, WAVE);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* K1a: exact frame-sequential top-N for one (utterance, codebook, stream) chain        */
+/* ---------------------------------------------------------------------------------- */
+
+struct ChainParams {
+    const float *rec;     /* [n_cb][n_feat][n_density][SSW_REC_FLOATS] */
+    const float *feats;   /* [n_frames][featdim] */
+    const int *utt_off;   /* [n_utts+1] (chain mode) */
+    const int *work;      /* fix-up mode: [n_work] packed (frame << 8 | cbf) run heads */
+    const uint32_t *carry_pk; /* optional [n_utts][n_cb*n_feat] packed cw order to start from */
+    uint32_t *topn_cw;    /* [n_frames][n_cb*n_feat] 4 x uint8 packed */
+    int4 *topn_sc;        /* [n_frames][n_cb*n_feat] raw scores */
+    const uint32_t *flags;/* fix-up mode: bit per (frame, cbf) */
+    const int *frame_utt_start; /* fix-up mode: [n_frames] first frame of the frame's utterance */
+    int n_utts, n_cbf, n_feat, featdim, ds, n_work, n_frames, frame_base;
+    int featoff[SSW_MAX_FEAT];
+};
+
+template <int NDL>
+struct LaneDens {
+    float d[NDL];
+    int i[NDL];
+};
+
+/* value of iv[] for density cw (cw wave-uniform) */
+template <int NDL>
+__device__ __forceinline__ int
+read_density_int(const int (&iv)[NDL], int cw)
+{
+    int lane = cw & 63, half = cw >> 6, v = 0;
+#pragma unroll
+    for (int h = 0; h < NDL; ++h) {
+        int t = __builtin_amdgcn_readlane(iv[h], lane);
+        v = (half == h) ? t : v;
+    }
+    return v;
+}
+
+/* One frame of the reference's top-N state machine on a wave that holds this frame's 64*NDL
+ * float densities (dv) and their truncated ints (iv), given last frame's codeword order Lc.
+ * Restates eval_topn + eval_cb (src/ptm_mgau.c:86-225) exactly:
+ *   1. re-score the carried codewords in carried order, each placed AFTER equal scores;
+ *   2. scan codewords ascending; admit when d >= (float)worst.score and not present; place
+ *      BEFORE equal scores; the worst drops off.  The scan is run as "find the next admissible
+ *      codeword with a ballot", so it costs one iteration per insertion, not per density. */
+template <int NDL, int TOPN>
+__device__ __forceinline__ void
+topn_exact_step(const float (&dv)[NDL], const int (&iv)[NDL], int (&Lc)[TOPN], int (&Ls)[TOPN],
+                bool do_scan)
+{
+    int nc[TOPN], ns[TOPN];
+#pragma unroll
+    for (int i = 0; i < TOPN; ++i) {
+        int c = Lc[i];
+        int s = read_density_int<NDL>(iv, c);
+        int pos = 0;
+#pragma unroll
+        for (int k = 0; k < i; ++k)
+            pos += (ns[k] >= s) ? 1 : 0;
+#pragma unroll
+        for (int k = i; k >= 1; --k)
+            if (k > pos) {
+                ns[k] = ns[k - 1];
+                nc[k] = nc[k - 1];
+            }
+#pragma unroll
+        for (int k = 0; k <= i; ++k)
+            if (k == pos) {
+                ns[k] = s;
+                nc[k] = c;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < TOPN; ++i) {
+        Lc[i] = nc[i];
+        Ls[i] = ns[i];
+    }
+    if (!do_scan)
+        return;
+
+    unsigned long long rem[NDL];
+#pragma unroll
+    for (int h = 0; h < NDL; ++h)
+        rem[h] = ~0ull;
+    for (;;) {
+        float thr = (float)Ls[TOPN - 1];
+        unsigned long long m[NDL];
+#pragma unroll
+        for (int h = 0; h < NDL; ++h)
+            m[h] = __ballot(dv[h] >= thr) & rem[h];
+#pragma unroll
+        for (int k = 0; k < TOPN; ++k) {
+            int c = Lc[k];
+#pragma unroll
+            for (int h = 0; h < NDL; ++h)
+                if ((c >> 6) == h)
+                    m[h] &= ~(1ull << (c & 63));
+        }
+        int cw = -1;
+#pragma unroll
+        for (int h = NDL - 1; h >= 0; --h)
+            if (m[h] != 0)
+                cw = h * 64 + __builtin_ctzll(m[h]);
+        if (cw < 0)
+            break;
+        /* everything up to and including cw has now been scanned */
+#pragma unroll
+        for (int h = 0; h < NDL; ++h) {
+            if (h < (cw >> 6))
+                rem[h] = 0;
+            else if (h == (cw >> 6))
+                rem[h] &= ~((2ull << (cw & 63)) - 1ull);
+        }
+        int s = read_density_int<NDL>(iv, cw);
+        int pos = 0;
+#pragma unroll
+        for (int k = 0; k < TOPN - 1; ++k)
+            pos += (Ls[k] > s) ? 1 : 0;
+#pragma unroll
+        for (int k = TOPN - 1; k >= 1; --k)
+            if (k > pos) {
+                Ls[k] = Ls[k - 1];
+                Lc[k] = Lc[k - 1];
+            }
+#pragma unroll
+        for (int k = 0; k < TOPN; ++k)
+            if (k == pos) {
+                Ls[k] = s;
+                Lc[k] = cw;
+            }
+    }
+}
+
+template <int VECLEN, int NDL>
+__device__ __forceinline__ void
+load_lane_gaussians(const float *rec_cbf, int lane, float (&mean)[NDL][VECLEN],
+                    float (&var)[NDL][VECLEN], float (&det)[NDL])
+{
+#pragma unroll
+    for (int h = 0; h < NDL; ++h) {
+        const float4 *r = reinterpret_cast<const float4 *>(rec_cbf
+                                                           + (size_t)(h * 64 + lane)
+                                                               * SSW_REC_FLOATS);
+        float buf[SSW_REC_FLOATS];
+#pragma unroll
+        for (int q = 0; q < SSW_REC_FLOATS / 4; ++q) {
+            float4 v = r[q];
+            buf[q * 4 + 0] = v.x;
+            buf[q * 4 + 1] = v.y;
+            buf[q * 4 + 2] = v.z;
+            buf[q * 4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < VECLEN; ++j) {
+            mean[h][j] = buf[j];
+            var[h][j] = buf[SSW_REC_VAR + j];
+        }
+        det[h] = buf[SSW_REC_DET];
+    }
+}
+
+/* MODE 0: one wave per (utterance, cbf) chain, all frames in order, history reset (or taken
+ *         from `carry_pk`).
+ * MODE 1: fix-up: one wave per work item = head of a run of flagged frames of one chain; the
+ *         carried order comes from the previous frame's final result in topn_cw. */
+template <int VECLEN, int NDL, int TOPN, int MODE>
+__global__ void __launch_bounds__(256)
+ptm_topn_chain_kernel(ChainParams P)
+{
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    int cbf, t0, t1, u = 0;
+    if (MODE == 0) {
+        if (wid >= P.n_utts * P.n_cbf)
+            return;
+        u = wid / P.n_cbf;
+        cbf = wid - u * P.n_cbf;
+        t0 = P.utt_off[u];
+        t1 = P.utt_off[u + 1];
+    } else {
+        if (wid >= P.n_work)
+            return;
+        int item = P.work[wid];
+        cbf = item & 0xff;
+        t0 = item >> 8;
+        t1 = P.n_frames; /* run ends at the first unflagged frame, checked below */
+    }
+    const int f = cbf % P.n_feat;
+    const float *rec_cbf = P.rec + (size_t)cbf * (NDL * 64) * SSW_REC_FLOATS;
+
+    float mean[NDL][VECLEN], var[NDL][VECLEN], det[NDL];
+    load_lane_gaussians<VECLEN, NDL>(rec_cbf, lane, mean, var, det);
+
+    int Lc[TOPN], Ls[TOPN];
+    int ustart = t0;
+    if (MODE == 1)
+        ustart = P.frame_utt_start[t0];
+    if (MODE == 1 && t0 > ustart) {
+        uint32_t pk = P.topn_cw[(size_t)(t0 - 1) * P.n_cbf + cbf];
+#pragma unroll
+        for (int k = 0; k < TOPN; ++k)
+            Lc[k] = (pk >> (8 * k)) & 0xff;
+    } else if (MODE == 0 && P.carry_pk != nullptr) {
+        uint32_t pk = P.carry_pk[(size_t)u * P.n_cbf + cbf];
+#pragma unroll
+        for (int k = 0; k < TOPN; ++k)
+            Lc[k] = (pk >> (8 * k)) & 0xff;
+    } else {
+#pragma unroll
+        for (int k = 0; k < TOPN; ++k)
+            Lc[k] = k; /* reset history: cw = m (src/ptm_mgau.c:709) */
+    }
+#pragma unroll
+    for (int k = 0; k < TOPN; ++k)
+        Ls[k] = INT_MIN;
+
+    for (int t = t0; t < t1; ++t) {
+        if (MODE == 1) {
+            /* stop at the end of this run of flagged frames (never cross an utterance start:
+             * frame_utt_start changes there and the next head owns it) */
+            size_t bit = (size_t)t * P.n_cbf + cbf;
+            bool flagged = (P.flags[bit >> 5] >> (bit & 31)) & 1u;
+            if (t > t0 && (!flagged || P.frame_utt_start[t] != ustart))
+                break;
+        }
+        const float *xp = P.feats + (size_t)t * P.featdim + P.featoff[f];
+        float x[VECLEN];
+#pragma unroll
+        for (int j = 0; j < VECLEN; ++j)
+            x[j] = xp[j];
+        float dv[NDL];
+        int iv[NDL];
+#pragma unroll
+        for (int h = 0; h < NDL; ++h) {
+            dv[h] = density<VECLEN>(x, mean[h], var[h], det[h]);
+            iv[h] = dens2int(dv[h]);
+        }
+        bool do_scan = ((t - ustart + P.frame_base) % P.ds) == 0; /* src/ptm_mgau.c:241 */
+        topn_exact_step<NDL, TOPN>(dv, iv, Lc, Ls, do_scan);
+        if (lane == 0) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int k = 0; k < TOPN; ++k)
+                pk |= (uint32_t)(Lc[k] & 0xff) << (8 * k);
+            P.topn_cw[(size_t)t * P.n_cbf + cbf] = pk;
+            static_assert(TOPN == 4, "score store is an int4");
+            P.topn_sc[(size_t)t * P.n_cbf + cbf] = make_int4(Ls[0], Ls[1], Ls[2], Ls[3]);
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* K1b: normalise the top-N block and combine it with the mixture weights              */
+/* ---------------------------------------------------------------------------------- */
+
+struct SenoneParams {
+    const uint32_t *topn_cw; /* [n_frames][n_cbf] */
+    const int4 *topn_sc;     /* [n_frames][n_cbf] raw */
+    const uint8_t *mixw;     /* [n_feat][n_density][sen_stride] */
+    const uint8_t *sen2cb;   /* [n_sen] */
+    const uint8_t *logadd8;  /* [256] */
+    int16_t *out;            /* [n_frames][n_sen] */
+    int n_frames, n_cb, n_feat, n_density, n_sen, sen_stride;
+};
+
+constexpr int SEN_THREADS = 1024;
+constexpr int SEN_MAX_PER_THREAD = 8; /* n_sen <= 8192 */
+
+template <int TOPN>
+__global__ void __launch_bounds__(SEN_THREADS)
+ptm_senone_kernel(SenoneParams P)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n_cbf = P.n_cb * P.n_feat;
+    /* LDS carve: logadd[256] | norm[n_feat] int | ns[n_cbf*TOPN] u8 | cw[n_cbf*TOPN] u8 | red */
+    uint8_t *s_tab = smem;
+    int *s_norm = reinterpret_cast<int *>(smem + 256);
+    uint8_t *s_ns = smem + 256 + 4 * SSW_MAX_FEAT;
+    uint8_t *s_cw = s_ns + ((n_cbf * TOPN + 15) & ~15);
+    int *s_red = reinterpret_cast<int *>(s_cw + ((n_cbf * TOPN + 15) & ~15));
+
+    const int t = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t *cwrow = P.topn_cw + (size_t)t * n_cbf;
+    const int4 *scrow = P.topn_sc + (size_t)t * n_cbf;
+
+    if (tid < 256)
+        s_tab[tid] = P.logadd8[tid];
+    /* per-stream normaliser: max over codebooks of (best >> 10), src/ptm_mgau.c:271-278 */
+    if (tid < P.n_feat) {
+        int norm = SSW_WORST_SCORE;
+        for (int c = 0; c < P.n_cb; ++c) {
+            int top = scrow[c * P.n_feat + tid].x >> SSW_SENSCR_SHIFT;
+            norm = norm < top ? top : norm;
+        }
+        s_norm[tid] = norm;
+    }
+    __syncthreads();
+    /* s = min(96, -((s >> 10) - norm)), src/ptm_mgau.c:284-290 */
+    for (int i = tid; i < n_cbf; i += SEN_THREADS) {
+        int4 sc = scrow[i];
+        uint32_t pk = cwrow[i];
+        int norm = s_norm[i % P.n_feat];
+        int v[4] = { sc.x, sc.y, sc.z, sc.w };
+#pragma unroll
+        for (int k = 0; k < TOPN; ++k) {
+            int s = -((v[k] >> SSW_SENSCR_SHIFT) - norm);
+            s = s > SSW_MAX_NEG_ASCR ? SSW_MAX_NEG_ASCR : s;
+            s_ns[i * TOPN + k] = (uint8_t)s;
+            s_cw[i * TOPN + k] = (uint8_t)(pk >> (8 * k));
+        }
+    }
+    __syncthreads();
+
+    /* senone combine, src/ptm_mgau.c:342-395 */
+    int asc[SEN_MAX_PER_THREAD];
+    int best = INT_MAX;
+#pragma unroll
+    for (int r = 0; r < SEN_MAX_PER_THREAD; ++r) {
+        int sen = r * SEN_THREADS + tid;
+        asc[r] = 0;
+        if (sen < P.n_sen) {
+            int cb = P.sen2cb[sen];
+            int a = 0;
+            for (int f = 0; f < P.n_feat; ++f) {
+                int base = (cb * P.n_feat + f) * TOPN;
+                const uint8_t *mw = P.mixw + (size_t)f * P.n_density * P.sen_stride + sen;
+                int fden = (int)mw[(size_t)s_cw[base] * P.sen_stride] + (int)s_ns[base];
+#pragma unroll
+                for (int k = 1; k < TOPN; ++k) {
+                    int y = (int)mw[(size_t)s_cw[base + k] * P.sen_stride] + (int)s_ns[base + k];
+                    /* fast_logmath_add, tied_mgau_common.h:100-117 */
+                    int d = fden > y ? fden - y : y - fden;
+                    int r2 = fden > y ? y : fden;
+                    fden = r2 - (int)s_tab[d];
+                }
+                a += fden;
+            }
+            asc[r] = a;
+            best = a < best ? a : best;
+        }
+    }
+    /* block minimum */
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        int o = __shfl_xor(best, off, WAVE);
+        best = o < best ? o : best;
+    }
+    if ((tid & 63) == 0)
+        s_red[tid >> 6] = best;
+    __syncthreads();
+    if (tid < SEN_THREADS / 64) {
+        int b = s_red[tid];
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            int o = __shfl_xor(b, off, WAVE);
+            b = o < b ? o : b;
+        }
+        if (tid == 0)
+            s_red[0] = b;
+    }
+    __syncthreads();
+    best = s_red[0];
+    int16_t *orow = P.out + (size_t)t * P.n_sen;
+#pragma unroll
+    for (int r = 0; r < SEN_MAX_PER_THREAD; ++r) {
+        int sen = r * SEN_THREADS + tid;
+        if (sen < P.n_sen) /* int16 arithmetic as in src/ptm_mgau.c:394-400 */
+            orow[sen] = (int16_t)((int16_t)asc[r] - (int16_t)best);
+    }
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* K2: forced-alignment Viterbi, one wave per utterance                                 */
+/* ---------------------------------------------------------------------------------- */
+
+struct AlignUtt {
+    int frame_off, n_frames, phone_off, n_phones;
+    long long tok_off; /* offset (in tokens) of this utterance's token stack */
+};
+
+struct AlignParams {
+    const int16_t *senscr; /* [total_frames][n_sen] */
+    const AlignUtt *utts;
+    const uint16_t *senid; /* [total_phones][3] */
+    const int16_t *tmatid; /* [total_phones] */
+    const int32_t *sf, *ef;
+    const uint8_t *tp; /* [n_tmat][12] */
+    int2 *tokens;
+    ssw_align_entry_t *state_io; /* [total_phones*3] */
+    int32_t *status;
+    int n_sen, n_utts, max_phones;
+};
+
+/* hmm_vit_eval_3st_lr, src/hmm.c:482-567.  n0..n2 are the NEGATED senone scores. */
+__device__ __forceinline__ int
+vit_eval_3st(int &s0, int &s1, int &s2, int &h0, int &h1, int &h2, int &os, int &oh, int n0,
+             int n1, int n2, uint32_t tpa, uint32_t tpb, uint32_t tpc)
+{
+#define TPQ(word, j) (-(int)(((word) >> (8 * (j))) & 0xffu))
+    const int tp00 = TPQ(tpa, 0), tp01 = TPQ(tpa, 1), tp02 = TPQ(tpa, 2);
+    const int tp11 = TPQ(tpb, 1), tp12 = TPQ(tpb, 2), tp13 = TPQ(tpb, 3);
+    const int tp22 = TPQ(tpc, 2), tp23 = TPQ(tpc, 3);
+#undef TPQ
+    int a2 = s2 + n2, a1 = s1 + n1, a0 = s0 + n0;
+    int best = SSW_WORST_SCORE;
+    int t0, t1, t2 = INT_MIN; /* t2 is deliberately not reset between the two blocks */
+
+    if (a1 > SSW_WORST_SCORE) {
+        int s3;
+        t1 = a2 + tp23;
+        if (tp13 > -255)
+            t2 = a1 + tp13;
+        if (t1 > t2) {
+            s3 = t1;
+            oh = h2;
+        } else {
+            s3 = t2;
+            oh = h1;
+        }
+        if (s3 < SSW_WORST_SCORE)
+            s3 = SSW_WORST_SCORE;
+        os = s3;
+        best = s3;
+    }
+    t0 = a2 + tp22;
+    t1 = a1 + tp12;
+    if (tp02 > -255)
+        t2 = a0 + tp02;
+    int ns2;
+    if (t0 > t1) {
+        if (t2 > t0) {
+            ns2 = t2;
+            h2 = h0;
+        } else
+            ns2 = t0;
+    } else {
+        if (t2 > t1) {
+            ns2 = t2;
+            h2 = h0;
+        } else {
+            ns2 = t1;
+            h2 = h1;
+        }
+    }
+    if (ns2 < SSW_WORST_SCORE)
+        ns2 = SSW_WORST_SCORE;
+    if (ns2 > best)
+        best = ns2;
+
+    int ns1;
+    t0 = a1 + tp11;
+    t1 = a0 + tp01;
+    if (t0 > t1) {
+        ns1 = t0;
+    } else {
+        ns1 = t1;
+        h1 = h0;
+    }
+    if (ns1 < SSW_WORST_SCORE)
+        ns1 = SSW_WORST_SCORE;
+    if (ns1 > best)
+        best = ns1;
+
+    int ns0 = a0 + tp00;
+    if (ns0 < SSW_WORST_SCORE)
+        ns0 = SSW_WORST_SCORE;
+    if (ns0 > best)
+        best = ns0;
+    s0 = ns0;
+    s1 = ns1;
+    s2 = ns2;
+    return best;
+}
+
+/* LDS layout: 16 int arrays of `P` (padded phone count) entries each. */
+enum { A_S0, A_S1, A_S2, A_H0, A_H1, A_H2, A_OS, A_OH, A_FR, A_TPA, A_TPB, A_TPC, A_SEN01,
+       A_SEN2, A_SF, A_EF, A_COUNT };
+
+__global__ void __launch_bounds__(64)
+viterbi_align_kernel(AlignParams P)
+{
+    extern __shared__ int lds[];
+    const int u = blockIdx.x;
+    const int lane = threadIdx.x;
+    const AlignUtt U = P.utts[u];
+    const int NP = U.n_phones;
+    const int PP = P.max_phones + 1; /* +1: slot NP is a never-active sentinel neighbour */
+    const int W = (NP + 63) >> 6;
+    const int n_states = NP * 3;
+#define L(arr, p) lds[(arr)*PP + (p)]
+
+    for (int p = lane; p <= NP; p += 64) {
+        bool real = p < NP;
+        int gp = U.phone_off + p;
+        L(A_S0, p) = SSW_WORST_SCORE; /* hmm_clear, src/hmm.c:124-140 */
+        L(A_S1, p) = SSW_WORST_SCORE;
+        L(A_S2, p) = SSW_WORST_SCORE;
+        L(A_H0, p) = -1;
+        L(A_H1, p) = -1;
+        L(A_H2, p) = -1;
+        L(A_OS, p) = SSW_WORST_SCORE;
+        L(A_OH, p) = -1;
+        L(A_FR, p) = -1;
+        if (real) {
+            const uint32_t *tp = reinterpret_cast<const uint32_t *>(P.tp)
+                + (size_t)P.tmatid[gp] * 3;
+            L(A_TPA, p) = (int)tp[0];
+            L(A_TPB, p) = (int)tp[1];
+            L(A_TPC, p) = (int)tp[2];
+            L(A_SEN01, p) = (int)P.senid[gp * 3] | ((int)P.senid[gp * 3 + 1] << 16);
+            L(A_SEN2, p) = (int)P.senid[gp * 3 + 2];
+            L(A_SF, p) = P.sf[gp];
+            L(A_EF, p) = P.ef[gp];
+        } else {
+            L(A_SF, p) = INT_MAX; /* nothing ever transitions into the sentinel */
+            L(A_EF, p) = INT_MAX;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) { /* state_align_search_start: hmm_enter(hmms, 0, 0, 0) */
+        L(A_S0, 0) = 0;
+        L(A_H0, 0) = 0;
+        L(A_FR, 0) = 0;
+    }
+    __syncthreads();
+
+    int2 *tok = P.tokens + U.tok_off;
+    int best_score = 0;
+    for (int t = 0; t < U.n_frames; ++t) {
+        const int16_t *row = P.senscr + (size_t)(U.frame_off + t) * P.n_sen;
+        const int nf = t + 1;
+        const bool renorm = (best_score - 0x300000) < SSW_WORST_SCORE;
+        int bs = SSW_WORST_SCORE;
+
+        /* renormalize_hmms + evaluate_hmms + prune_hmms (state_align_search.c:57-106) */
+        for (int w = 0; w < W; ++w) {
+            int p = w * 64 + lane;
+            if (p < NP) {
+                int s0 = L(A_S0, p), s1 = L(A_S1, p), s2 = L(A_S2, p), os = L(A_OS, p);
+                int fr = L(A_FR, p);
+                if (renorm) { /* hmm_normalize, src/hmm.c:150-161 */
+                    if (s0 > SSW_WORST_SCORE)
+                        s0 -= best_score;
+                    if (s1 > SSW_WORST_SCORE)
+                        s1 -= best_score;
+                    if (s2 > SSW_WORST_SCORE)
+                        s2 -= best_score;
+                    if (os > SSW_WORST_SCORE)
+                        os -= best_score;
+                }
+                if (fr >= t) {
+                    int h0 = L(A_H0, p), h1 = L(A_H1, p), h2 = L(A_H2, p), oh = L(A_OH, p);
+                    int sen01 = L(A_SEN01, p), sen2 = L(A_SEN2, p);
+                    int n0 = -(int)row[sen01 & 0xffff];
+                    int n1 = -(int)row[(sen01 >> 16) & 0xffff];
+                    int n2 = -(int)row[sen2];
+                    int b = vit_eval_3st(s0, s1, s2, h0, h1, h2, os, oh, n0, n1, n2,
+                                         (uint32_t)L(A_TPA, p), (uint32_t)L(A_TPB, p),
+                                         (uint32_t)L(A_TPC, p));
+                    bs = b > bs ? b : bs;
+                    L(A_H1, p) = h1;
+                    L(A_H2, p) = h2;
+                    L(A_OH, p) = oh;
+                    if (nf <= L(A_EF, p))
+                        L(A_FR, p) = nf;
+                }
+                L(A_S0, p) = s0;
+                L(A_S1, p) = s1;
+                L(A_S2, p) = s2;
+                L(A_OS, p) = os;
+            }
+        }
+        best_score = wave_max_i32(bs);
+        __syncthreads();
+
+        /* phone_transition (state_align_search.c:108-133) as a carry chain, then
+         * record_transitions (:149-175).  entered(i+1) = C_i & (A_i | entered(i)) is the carry
+         * recurrence of the binary sum X + Y with X = C, Y = A & C. */
+        unsigned long long cin = 0;
+        int2 *tkrow = tok + (size_t)t * n_states;
+        for (int w = 0; w < W; ++w) {
+            int p = w * 64 + lane;
+            bool valid = p < NP;
+            int fr = valid ? L(A_FR, p) : -1;
+            bool a_bit = valid && fr == nf;
+            bool c_bit = false;
+            if (valid && p + 1 < NP) {
+                int nfr = L(A_FR, p + 1);
+                c_bit = (nf >= L(A_SF, p + 1)) && (nfr < t || L(A_OS, p) > L(A_S0, p + 1));
+            }
+            unsigned long long A = __ballot(a_bit), Cm = __ballot(c_bit);
+            unsigned long long X = Cm, Y = A & Cm;
+            unsigned long long S = X + Y + cin;
+            unsigned long long E = S ^ X ^ Y; /* bit i: phone (w*64+i) is entered */
+            unsigned long long cout = ((X & Y) | ((X | Y) & ~S)) >> 63;
+            bool entered = (E >> lane) & 1ull;
+            int src_os = 0, src_oh = 0;
+            if (valid && entered) { /* p >= 1 whenever entered */
+                src_os = L(A_OS, p - 1);
+                src_oh = L(A_OH, p - 1);
+            }
+            __syncthreads(); /* all reads of neighbours done before this word's writes */
+            if (valid) {
+                if (entered) { /* hmm_enter, src/hmm.c:142-148 */
+                    L(A_S0, p) = src_os;
+                    L(A_H0, p) = src_oh;
+                    L(A_FR, p) = nf;
+                    fr = nf;
+                }
+                int2 k0 = make_int2(-1, -1), k1 = k0, k2 = k0;
+                if (fr >= t) {
+                    k0 = make_int2(L(A_H0, p), L(A_S0, p));
+                    k1 = make_int2(L(A_H1, p), L(A_S1, p));
+                    k2 = make_int2(L(A_H2, p), L(A_S2, p));
+                    L(A_H0, p) = p * 3;
+                    L(A_H1, p) = p * 3 + 1;
+                    L(A_H2, p) = p * 3 + 2;
+                }
+                tkrow[p * 3] = k0;
+                tkrow[p * 3 + 1] = k1;
+                tkrow[p * 3 + 2] = k2;
+            }
+            cin = cout;
+            __syncthreads();
+        }
+    }
+
+    /* state_align_search_finish (state_align_search.c:215-268) */
+    __threadfence();
+    __syncthreads();
+    if (lane == 0) {
+        ssw_align_entry_t *st = P.state_io + (size_t)U.phone_off * 3;
+        int last_id = L(A_OH, NP - 1), cur_id = last_id;
+        int last_score = L(A_OS, NP - 1);
+        int status = 0;
+        if (last_id == -1) {
+            status = -1;
+        } else {
+            int last_frame = U.n_frames;
+            for (int cf = U.n_frames - 2; cf >= 0; --cf) {
+                int2 cur = tok[(size_t)cf * n_states + cur_id];
+                cur_id = cur.x;
+                if (cur_id == -1) {
+                    status = -(2 + cf);
+                    break;
+                }
+                if (cur_id != last_id) {
+                    st[last_id].start = cf + 1;
+                    st[last_id].duration = last_frame - (cf + 1);
+                    st[last_id].score = last_score - cur.y;
+                    last_id = cur_id;
+                    last_score = cur.y;
+                    last_frame = cf + 1;
+                }
+            }
+            if (status == 0) {
+                st[0].start = 0;
+                st[0].duration = last_frame;
+            }
+        }
+        P.status[u] = status;
+    }
+#undef L
+}
+
+} // namespace
+
+/* ==================================================================================== */
+/* Host side: device model + C ABI                                                      */
+/* ==================================================================================== */
+
+struct ssw_model_s {
+    ssw_host_model_t *h;
+    int device;
+    int n_cbf, sen_stride;
+    float *d_rec;
+    uint8_t *d_mixw, *d_sen2cb, *d_logadd8, *d_tp;
+    /* scoring workspace */
+    uint32_t *d_topn_cw;
+    int4 *d_topn_sc;
+    int *d_utt_off;
+    size_t ws_frames, ws_utts;
+    int last_n_frames;
+    int64_t stats[2];
+    /* host-API staging */
+    float *d_feats;
+    int16_t *d_out;
+    size_t st_frames;
+};
+
+template <typename T>
+static int
+dev_alloc(T **p, size_t n)
+{
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T)));
+    return 0;
+}
+
+static int
+upload_model(ssw_model_s *m)
+{
+    const ssw_host_model_t *h = m->h;
+    const int ncbf = h->n_cb * h->n_feat;
+    m->n_cbf = ncbf;
+    /* Gaussian records */
+    std::vector<float> rec((size_t)ncbf * h->n_density * SSW_REC_FLOATS, 0.0f);
+    const float *mp = h->mean, *vp = h->var;
+    for (int c = 0; c < h->n_cb; ++c)
+        for (int f = 0; f < h->n_feat; ++f)
+            for (int d = 0; d < h->n_density; ++d) {
+                float *r = rec.data()
+                    + (((size_t)c * h->n_feat + f) * h->n_density + d) * SSW_REC_FLOATS;
+                for (int j = 0; j < h->veclen[f]; ++j) {
+                    r[j] = *mp++;
+                    r[SSW_REC_VAR + j] = *vp++;
+                }
+                r[SSW_REC_DET] = h->det[((size_t)c * h->n_feat + f) * h->n_density + d];
+            }
+    if (dev_alloc(&m->d_rec, rec.size()) < 0)
+        return -1;
+    HIP_OK(hipMemcpy(m->d_rec, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc((void **)&m->d_logadd8, 256));
+    HIP_OK(hipMemcpy(m->d_logadd8, h->logadd8, 256, hipMemcpyHostToDevice));
+    if (h->n_sen) {
+        std::vector<uint8_t> s2c((size_t)h->n_sen);
+        for (int i = 0; i < h->n_sen; ++i)
+            s2c[i] = (uint8_t)h->sen2cb[i];
+        HIP_OK(hipMalloc((void **)&m->d_sen2cb, s2c.size()));
+        HIP_OK(hipMemcpy(m->d_sen2cb, s2c.data(), s2c.size(), hipMemcpyHostToDevice));
+    }
+    if (h->ptm_mixw) {
+        m->sen_stride = (h->n_sen + 127) & ~127;
+        std::vector<uint8_t> mw((size_t)h->n_feat * h->n_density * m->sen_stride, 0);
+        for (int r = 0; r < h->n_feat * h->n_density; ++r)
+            memcpy(mw.data() + (size_t)r * m->sen_stride, h->ptm_mixw + (size_t)r * h->n_sen,
+                   (size_t)h->n_sen);
+        HIP_OK(hipMalloc((void **)&m->d_mixw, mw.size()));
+        HIP_OK(hipMemcpy(m->d_mixw, mw.data(), mw.size(), hipMemcpyHostToDevice));
+    }
+    if (h->tp) {
+        size_t n = (size_t)h->tp_n_tmat * h->tp_n_state * (h->tp_n_state + 1);
+        HIP_OK(hipMalloc((void **)&m->d_tp, n + 16));
+        HIP_OK(hipMemcpy(m->d_tp, h->tp, n, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+extern "C" ssw_model_t *
+ssw_model_load(const char *mdef, const char *means, const char *variances, const char *sendump,
+               const char *mixw, const char *tmat, const ssw_config_t *cfg)
+{
+    ssw_host_model_t *h = ssw_host_model_load(mdef, means, variances, sendump, mixw, tmat, cfg);
+    if (h == NULL)
+        return NULL;
+    for (int f = 0; f < h->n_feat; ++f)
+        if (h->veclen[f] > SSW_MAX_VECLEN) {
+            ssw_set_error("stream %d has %d dimensions; the gfx950 kernels handle <= %d", f,
+                          h->veclen[f], SSW_MAX_VECLEN);
+            ssw_host_model_free(h);
+            return NULL;
+        }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        ssw_set_error("no HIP device: the MI355X path has no CPU fallback");
+        ssw_host_model_free(h);
+        return NULL;
+    }
+    ssw_model_s *m = new ssw_model_s();
+    memset(m, 0, sizeof(*m));
+    m->h = h;
+    if (h->cfg.device >= 0) {
+        if (hipSetDevice(h->cfg.device) != hipSuccess) {
+            ssw_set_error("hipSetDevice(%d) failed", h->cfg.device);
+            ssw_model_free(m);
+            return NULL;
+        }
+        m->device = h->cfg.device;
+    } else
+        (void)hipGetDevice(&m->device);
+    if (upload_model(m) < 0) {
+        ssw_model_free(m);
+        return NULL;
+    }
+    return m;
+}
+
+extern "C" void
+ssw_model_free(ssw_model_t *m)
+{
+    if (m == NULL)
+        return;
+    (void)hipFree(m->d_rec);
+    (void)hipFree(m->d_mixw);
+    (void)hipFree(m->d_sen2cb);
+    (void)hipFree(m->d_logadd8);
+    (void)hipFree(m->d_tp);
+    (void)hipFree(m->d_topn_cw);
+    (void)hipFree(m->d_topn_sc);
+    (void)hipFree(m->d_utt_off);
+    (void)hipFree(m->d_feats);
+    (void)hipFree(m->d_out);
+    ssw_host_model_free(m->h);
+    delete m;
+}
+
+extern "C" int
+ssw_model_info(const ssw_model_t *m, ssw_model_info_t *o)
+{
+    const ssw_host_model_t *h = m->h;
+    memset(o, 0, sizeof(*o));
+    o->n_cb = h->n_cb;
+    o->n_feat = h->n_feat;
+    o->n_density = h->n_density;
+    o->veclen_total = h->veclen_total;
+    o->n_sen = h->n_sen;
+    o->n_ci_sen = h->n_ci_sen;
+    o->n_ciphone = h->n_ciphone;
+    o->n_phone = h->n_phone;
+    o->n_emit_state = h->n_emit_state;
+    o->n_tmat = h->tp ? h->tp_n_tmat : h->n_tmat;
+    o->n_sseq = h->n_sseq;
+    o->sil = h->sil;
+    o->n_floored = h->n_floored;
+    o->topn = h->cfg.topn;
+    o->has_ptm = h->ptm_mixw != NULL;
+    o->has_ms = h->ms_pdf != NULL;
+    o->device = m->device;
+    for (int f = 0; f < h->n_feat && f < 8; ++f)
+        o->veclen[f] = h->veclen[f];
+    return 0;
+}
+
+extern "C" const void *
+ssw_model_table(const ssw_model_t *m, int which, size_t *nbytes)
+{
+    const ssw_host_model_t *h = m->h;
+    size_t gau = (size_t)h->n_cb * h->n_density * h->veclen_total * sizeof(float);
+    size_t n = 0;
+    const void *p = NULL;
+    switch (which) {
+    case SSW_TAB_MEAN: p = h->mean; n = gau; break;
+    case SSW_TAB_VAR: p = h->var; n = gau; break;
+    case SSW_TAB_DET: p = h->det; n = (size_t)h->n_cb * h->n_feat * h->n_density * 4; break;
+    case SSW_TAB_PTM_MIXW: p = h->ptm_mixw; n = (size_t)h->n_feat * h->n_density * h->n_sen; break;
+    case SSW_TAB_MS_PDF: p = h->ms_pdf; n = (size_t)h->n_feat * h->n_density * h->n_sen; break;
+    case SSW_TAB_TP: p = h->tp; n = (size_t)h->tp_n_tmat * h->tp_n_state * (h->tp_n_state + 1); break;
+    case SSW_TAB_SSEQ: p = h->sseq; n = (size_t)h->n_sseq * h->n_emit_state * 2; break;
+    case SSW_TAB_SEN2CB: p = h->sen2cb; n = (size_t)h->n_sen * 2; break;
+    case SSW_TAB_LOGADD8: p = h->logadd8; n = 256; break;
+    case SSW_TAB_PHONE_SSID: p = h->phone_ssid; n = (size_t)h->n_phone * 4; break;
+    case SSW_TAB_PHONE_TMAT: p = h->phone_tmat; n = (size_t)h->n_phone * 4; break;
+    default: break;
+    }
+    if (p == NULL)
+        n = 0;
+    if (nbytes)
+        *nbytes = n;
+    return p;
+}
+
+/* ---------------------------------------------------------------------------------- */
+static int
+ensure_score_ws(ssw_model_s *m, int n_frames, int n_utts)
+{
+    if ((size_t)n_frames > m->ws_frames) {
+        (void)hipFree(m->d_topn_cw);
+        (void)hipFree(m->d_topn_sc);
+        m->d_topn_cw = NULL;
+        m->d_topn_sc = NULL;
+        m->ws_frames = 0;
+        if (dev_alloc(&m->d_topn_cw, (size_t)n_frames * m->n_cbf) < 0
+            || dev_alloc(&m->d_topn_sc, (size_t)n_frames * m->n_cbf) < 0)
+            return -1;
+        m->ws_frames = (size_t)n_frames;
+    }
+    if ((size_t)n_utts + 1 > m->ws_utts) {
+        (void)hipFree(m->d_utt_off);
+        m->d_utt_off = NULL;
+        m->ws_utts = 0;
+        if (dev_alloc(&m->d_utt_off, (size_t)n_utts + 1) < 0)
+            return -1;
+        m->ws_utts = (size_t)n_utts + 1;
+    }
+    return 0;
+}
+
+static int
+check_ptm_shape(const ssw_model_s *m)
+{
+    const ssw_host_model_t *h = m->h;
+    if (h->ptm_mixw == NULL) {
+        ssw_set_error("model has no PTM mixture weights (sendump / mixw)");
+        return -1;
+    }
+    if (h->n_density != 128 || h->cfg.topn != 4 || h->n_cb > 255) {
+        ssw_set_error("PTM kernels are built for 128 densities, top-4, <= 255 codebooks "
+                      "(model: %d densities, topn %d, %d codebooks)",
+                      h->n_density, h->cfg.topn, h->n_cb);
+        return -1;
+    }
+    for (int f = 0; f < h->n_feat; ++f)
+        if (h->veclen[f] != 13) {
+            ssw_set_error("PTM kernels are built for 13-dimensional streams");
+            return -1;
+        }
+    if (h->n_sen > SEN_THREADS * SEN_MAX_PER_THREAD) {
+        ssw_set_error("too many senones (%d)", h->n_sen);
+        return -1;
+    }
+    return 0;
+}
+
+static void
+fill_chain_params(const ssw_model_s *m, ChainParams &P, const float *d_feats)
+{
+    const ssw_host_model_t *h = m->h;
+    memset(&P, 0, sizeof(P));
+    P.rec = m->d_rec;
+    P.feats = d_feats;
+    P.utt_off = m->d_utt_off;
+    P.topn_cw = m->d_topn_cw;
+    P.topn_sc = m->d_topn_sc;
+    P.n_cbf = m->n_cbf;
+    P.n_feat = h->n_feat;
+    P.featdim = h->veclen_total;
+    P.ds = h->cfg.ds < 1 ? 1 : h->cfg.ds;
+    for (int f = 0; f < h->n_feat; ++f)
+        P.featoff[f] = h->featoff[f];
+}
+
+static int
+launch_senone(ssw_model_s *m, int n_frames, const uint32_t *cw, const int4 *sc, int16_t *d_out,
+              hipStream_t st)
+{
+    const ssw_host_model_t *h = m->h;
+    SenoneParams S;
+    S.topn_cw = cw;
+    S.topn_sc = sc;
+    S.mixw = m->d_mixw;
+    S.sen2cb = m->d_sen2cb;
+    S.logadd8 = m->d_logadd8;
+    S.out = d_out;
+    S.n_frames = n_frames;
+    S.n_cb = h->n_cb;
+    S.n_feat = h->n_feat;
+    S.n_density = h->n_density;
+    S.n_sen = h->n_sen;
+    S.sen_stride = m->sen_stride;
+    size_t part = ((size_t)m->n_cbf * 4 + 15) & ~(size_t)15;
+    size_t lds = 256 + 4 * SSW_MAX_FEAT + 2 * part + 64 * sizeof(int);
+    hipLaunchKernelGGL(ptm_senone_kernel<4>, dim3(n_frames), dim3(SEN_THREADS), lds, st, S);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int
+ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_frames,
+                const int32_t *utt_off, int32_t n_utts, int16_t *d_out, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n_frames == 0 || n_utts == 0)
+        return 0;
+    if (n_frames < 0 || n_utts < 0 || utt_off == NULL || utt_off[0] != 0
+        || utt_off[n_utts] != n_frames) {
+        ssw_set_error("bad utterance offsets");
+        return -1;
+    }
+    for (int u = 0; u < n_utts; ++u)
+        if (utt_off[u + 1] < utt_off[u]) {
+            ssw_set_error("utterance offsets must be non-decreasing");
+            return -1;
+        }
+    if (scorer != SSW_SCORER_PTM) {
+        ssw_set_error("scorer %d not available in this build", scorer);
+        return -1;
+    }
+    if (check_ptm_shape(m) < 0)
+        return -1;
+    HIP_OK(hipSetDevice(m->device));
+    if (ensure_score_ws(m, n_frames, n_utts) < 0)
+        return -1;
+    HIP_OK(hipMemcpyAsync(m->d_utt_off, utt_off, sizeof(int32_t) * ((size_t)n_utts + 1),
+                          hipMemcpyHostToDevice, st));
+    ChainParams P;
+    fill_chain_params(m, P, d_feats);
+    P.n_utts = n_utts;
+    int n_chain = n_utts * m->n_cbf;
+    hipLaunchKernelGGL((ptm_topn_chain_kernel<13, 2, 4, 0>), dim3((n_chain + 3) / 4), dim3(256),
+                       0, st, P);
+    HIP_OK(hipGetLastError());
+    if (launch_senone(m, n_frames, m->d_topn_cw, m->d_topn_sc, d_out, st) < 0)
+        return -1;
+    m->last_n_frames = n_frames;
+    m->stats[0] = (int64_t)n_frames * m->n_cbf;
+    m->stats[1] = (int64_t)n_frames * m->n_cbf;
+    return 0;
+}
+
+extern "C" int
+ssw_score_batch_host(ssw_model_t *m, int scorer, const float *feats, int32_t n_frames,
+                     const int32_t *utt_off, int32_t n_utts, int16_t *out)
+{
+    const ssw_host_model_t *h = m->h;
+    if (n_frames <= 0)
+        return 0;
+    HIP_OK(hipSetDevice(m->device));
+    if ((size_t)n_frames > m->st_frames) {
+        (void)hipFree(m->d_feats);
+        (void)hipFree(m->d_out);
+        m->d_feats = NULL;
+        m->d_out = NULL;
+        m->st_frames = 0;
+        if (dev_alloc(&m->d_feats, (size_t)n_frames * h->veclen_total) < 0
+            || dev_alloc(&m->d_out, (size_t)n_frames * h->n_sen) < 0)
+            return -1;
+        m->st_frames = (size_t)n_frames;
+    }
+    HIP_OK(hipMemcpy(m->d_feats, feats, sizeof(float) * (size_t)n_frames * h->veclen_total,
+                     hipMemcpyHostToDevice));
+    if (ssw_score_batch(m, scorer, m->d_feats, n_frames, utt_off, n_utts, m->d_out, NULL) < 0)
+        return -1;
+    HIP_OK(hipMemcpy(out, m->d_out, sizeof(int16_t) * (size_t)n_frames * h->n_sen,
+                     hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int
+ssw_score_batch_topn(ssw_model_t *m, int32_t n_frames, uint8_t *cw, int32_t *score)
+{
+    if (n_frames > m->last_n_frames) {
+        ssw_set_error("only %d frames were scored", m->last_n_frames);
+        return -1;
+    }
+    HIP_OK(hipSetDevice(m->device));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(cw, m->d_topn_cw, (size_t)n_frames * m->n_cbf * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(score, m->d_topn_sc, (size_t)n_frames * m->n_cbf * 16,
+                     hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int
+ssw_score_batch_stats(ssw_model_t *m, int64_t stats[2])
+{
+    stats[0] = m->stats[0];
+    stats[1] = m->stats[1];
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* alignment                                                                            */
+/* ---------------------------------------------------------------------------------- */
+extern "C" int
+ssw_align_batch(ssw_model_t *m, const int16_t *d_senscr, int32_t n_utts,
+                const int32_t *frame_off, const int32_t *phone_off, const uint16_t *senid,
+                const int16_t *tmatid, const int32_t *sf, const int32_t *ef,
+                ssw_align_entry_t *state_io, int32_t *status, void *stream)
+{
+    const ssw_host_model_t *h = m->h;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_utts <= 0)
+        return 0;
+    if (h->tp == NULL || h->tp_n_state != 3) {
+        ssw_set_error("alignment kernel needs 3-state transition matrices");
+        return -1;
+    }
+    HIP_OK(hipSetDevice(m->device));
+    const int total_phones = phone_off[n_utts];
+    std::vector<AlignUtt> utts((size_t)n_utts);
+    long long tok_total = 0;
+    int max_phones = 0;
+    for (int u = 0; u < n_utts; ++u) {
+        AlignUtt &U = utts[u];
+        U.frame_off = frame_off[u];
+        U.n_frames = frame_off[u + 1] - frame_off[u];
+        U.phone_off = phone_off[u];
+        U.n_phones = phone_off[u + 1] - phone_off[u];
+        U.tok_off = tok_total;
+        if (U.n_phones < 1 || U.n_frames < 0) {
+            ssw_set_error("utterance %d: %d phones, %d frames", u, U.n_phones, U.n_frames);
+            return -1;
+        }
+        tok_total += (long long)U.n_frames * U.n_phones * 3;
+        max_phones = U.n_phones > max_phones ? U.n_phones : max_phones;
+    }
+    for (int p = 0; p < total_phones; ++p)
+        if (tmatid[p] < 0 || tmatid[p] >= h->tp_n_tmat) {
+            ssw_set_error("phone %d: transition matrix %d out of range", p, tmatid[p]);
+            return -1;
+        }
+    size_t lds = (size_t)A_COUNT * (max_phones + 1) * sizeof(int);
+    if (lds > 160 * 1024) {
+        ssw_set_error("utterance with %d phones exceeds the LDS-resident limit", max_phones);
+        return -1;
+    }
+    AlignUtt *d_utts = NULL;
+    uint16_t *d_senid = NULL;
+    int16_t *d_tmatid = NULL;
+    int32_t *d_sf = NULL, *d_ef = NULL, *d_status = NULL;
+    int2 *d_tok = NULL;
+    ssw_align_entry_t *d_state = NULL;
+    int rv = -1;
+#define TRY(expr)                                                                            \
+    if ((expr) != hipSuccess) {                                                              \
+        ssw_set_error("%s failed: %s", #expr, hipGetErrorString(hipGetLastError()));         \
+        goto out;                                                                            \
+    }
+    TRY(hipMalloc((void **)&d_utts, sizeof(AlignUtt) * n_utts));
+    TRY(hipMalloc((void **)&d_senid, sizeof(uint16_t) * 3 * (size_t)total_phones + 16));
+    TRY(hipMalloc((void **)&d_tmatid, sizeof(int16_t) * (size_t)total_phones + 16));
+    TRY(hipMalloc((void **)&d_sf, sizeof(int32_t) * (size_t)total_phones));
+    TRY(hipMalloc((void **)&d_ef, sizeof(int32_t) * (size_t)total_phones));
+    TRY(hipMalloc((void **)&d_status, sizeof(int32_t) * n_utts));
+    TRY(hipMalloc((void **)&d_tok, sizeof(int2) * (size_t)(tok_total > 0 ? tok_total : 1)));
+    TRY(hipMalloc((void **)&d_state, sizeof(ssw_align_entry_t) * 3 * (size_t)total_phones));
+    TRY(hipMemcpyAsync(d_utts, utts.data(), sizeof(AlignUtt) * n_utts, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_senid, senid, sizeof(uint16_t) * 3 * (size_t)total_phones,
+                       hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_tmatid, tmatid, sizeof(int16_t) * (size_t)total_phones,
+                       hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_sf, sf, sizeof(int32_t) * (size_t)total_phones, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_ef, ef, sizeof(int32_t) * (size_t)total_phones, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_state, state_io, sizeof(ssw_align_entry_t) * 3 * (size_t)total_phones,
+                       hipMemcpyHostToDevice, st));
+    {
+        AlignParams A;
+        A.senscr = d_senscr;
+        A.utts = d_utts;
+        A.senid = d_senid;
+        A.tmatid = d_tmatid;
+        A.sf = d_sf;
+        A.ef = d_ef;
+        A.tp = m->d_tp;
+        A.tokens = d_tok;
+        A.state_io = d_state;
+        A.status = d_status;
+        A.n_sen = h->n_sen;
+        A.n_utts = n_utts;
+        A.max_phones = max_phones;
+        if (lds > 64 * 1024)
+            TRY(hipFuncSetAttribute((const void *)viterbi_align_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(viterbi_align_kernel, dim3(n_utts), dim3(64), lds, st, A);
+        TRY(hipGetLastError());
+    }
+    TRY(hipMemcpyAsync(state_io, d_state, sizeof(ssw_align_entry_t) * 3 * (size_t)total_phones,
+                       hipMemcpyDeviceToHost, st));
+    TRY(hipMemcpyAsync(status, d_status, sizeof(int32_t) * n_utts, hipMemcpyDeviceToHost, st));
+    TRY(hipStreamSynchronize(st));
+    rv = 0;
+out:
+#undef TRY
+    (void)hipFree(d_utts);
+    (void)hipFree(d_senid);
+    (void)hipFree(d_tmatid);
+    (void)hipFree(d_sf);
+    (void)hipFree(d_ef);
+    (void)hipFree(d_status);
+    (void)hipFree(d_tok);
+    (void)hipFree(d_state);
+    return rv;
+}
+
+extern "C" int
+ssw_alignment_propagate(const ssw_align_entry_t *child, const int32_t *parent, int32_t n_child,
+                        ssw_align_entry_t *parent_out, int32_t n_parent)
+{
+    int last = -1;
+    for (int i = 0; i < n_child; ++i) {
+        int p = parent[i];
+        if (p < 0 || p >= n_parent) {
+            ssw_set_error("child %d has parent %d of %d", i, p, n_parent);
+            return -1;
+        }
+        if (p != last) { /* src/ps_alignment.c:326-330 */
+            parent_out[p].start = child[i].start;
+            parent_out[p].duration = 0;
+            parent_out[p].score = 0;
+        }
+        parent_out[p].duration += child[i].duration;
+        parent_out[p].score += child[i].score;
+        last = p;
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* scorer object: mgau_t / mgaufuncs_t drop-in                                          */
+/* ---------------------------------------------------------------------------------- */
+struct ssw_mgau_impl {
+    ssw_mgau_s base; /* must be first: {vt, frame_idx} as in acmod.h:108-111 */
+    ssw_model_s *m;
+    int scorer;
+    /* one-frame path: the reference's 2-deep history ring (src/ptm_mgau.c:425-448) */
+    uint32_t *d_hist_cw[2];
+    int4 *d_hist_sc[2];
+    int *d_utt1;
+    float *d_feat1;
+    int16_t *d_out1;
+    /* whole-utterance cache filled by ssw_mgau_prescore */
+    std::vector<int16_t> cache;
+    int cache_frames;
+};
+
+static int mgau_frame_eval(ssw_mgau_t *mg, int16_t *senscr, uint8_t *senone_active,
+                           int32_t n_senone_active, float **feat, int32_t frame,
+                           int32_t compallsen);
+static int mgau_transform(ssw_mgau_t *mg, void *mllr);
+static void mgau_free(ssw_mgau_t *mg);
+
+static ssw_mgaufuncs_t g_ptm_funcs = { "ptm", mgau_frame_eval, mgau_transform, mgau_free };
+
+static int
+mgau_reset_device_hist(ssw_mgau_impl *g)
+{
+    std::vector<uint32_t> init((size_t)g->m->n_cbf, 0x03020100u); /* cw = m */
+    for (int i = 0; i < 2; ++i)
+        HIP_OK(hipMemcpy(g->d_hist_cw[i], init.data(), init.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" ssw_mgau_t *
+ssw_ptm_mgau_init(ssw_model_t *m)
+{
+    if (check_ptm_shape(m) < 0)
+        return NULL;
+    if (hipSetDevice(m->device) != hipSuccess) {
+        ssw_set_error("hipSetDevice failed");
+        return NULL;
+    }
+    ssw_mgau_impl *g = new ssw_mgau_impl();
+    g->base.vt = &g_ptm_funcs;
+    g->base.frame_idx = 0;
+    g->m = m;
+    g->scorer = SSW_SCORER_PTM;
+    g->cache_frames = 0;
+    g->d_utt1 = NULL;
+    g->d_feat1 = NULL;
+    g->d_out1 = NULL;
+    for (int i = 0; i < 2; ++i) {
+        g->d_hist_cw[i] = NULL;
+        g->d_hist_sc[i] = NULL;
+    }
+    bool ok = true;
+    for (int i = 0; i < 2 && ok; ++i)
+        ok = dev_alloc(&g->d_hist_cw[i], (size_t)m->n_cbf) == 0
+            && dev_alloc(&g->d_hist_sc[i], (size_t)m->n_cbf) == 0;
+    ok = ok && dev_alloc(&g->d_utt1, 2) == 0 && dev_alloc(&g->d_feat1, (size_t)m->h->veclen_total) == 0
+        && dev_alloc(&g->d_out1, (size_t)m->h->n_sen) == 0;
+    int one[2] = { 0, 1 };
+    ok = ok && hipMemcpy(g->d_utt1, one, sizeof(one), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && mgau_reset_device_hist(g) == 0;
+    if (!ok) {
+        mgau_free(&g->base);
+        return NULL;
+    }
+    return &g->base;
+}
+
+extern "C" ssw_mgau_t *
+ssw_ms_mgau_init(ssw_model_t *m)
+{
+    (void)m;
+    ssw_set_error("the ms scorer is not built yet (SURVEY section 8, kernel 3)");
+    return NULL;
+}
+
+extern "C" void
+ssw_mgau_reset_hist(ssw_mgau_t *mg)
+{
+    ssw_mgau_impl *g = reinterpret_cast<ssw_mgau_impl *>(mg);
+    (void)hipSetDevice(g->m->device);
+    (void)mgau_reset_device_hist(g);
+    g->cache_frames = 0;
+}
+
+extern "C" int
+ssw_mgau_prescore(ssw_mgau_t *mg, const float *feats, int32_t n_frames)
+{
+    ssw_mgau_impl *g = reinterpret_cast<ssw_mgau_impl *>(mg);
+    g->cache_frames = 0;
+    if (n_frames <= 0)
+        return 0;
+    g->cache.resize((size_t)n_frames * g->m->h->n_sen);
+    int32_t off[2] = { 0, n_frames };
+    if (ssw_score_batch_host(g->m, g->scorer, feats, n_frames, off, 1, g->cache.data()) < 0)
+        return -1;
+    g->cache_frames = n_frames;
+    return 0;
+}
+
+/* frame_eval slot of mgaufuncs_t (acmod.h:96-102); semantics of ptm_mgau_frame_eval
+ * (src/ptm_mgau.c:408-454) for compallsen = yes. */
+static int
+mgau_frame_eval(ssw_mgau_t *mg, int16_t *senscr, uint8_t *senone_active,
+                int32_t n_senone_active, float **feat, int32_t frame, int32_t compallsen)
+{
+    ssw_mgau_impl *g = reinterpret_cast<ssw_mgau_impl *>(mg);
+    ssw_model_s *m = g->m;
+    const ssw_host_model_t *h = m->h;
+    (void)senone_active;
+    (void)n_senone_active;
+    if (!compallsen) {
+        ssw_set_error("frame_eval with compallsen=no is not built yet (SURVEY section 8(f) row 3)");
+        return -1;
+    }
+    if (frame < 0) {
+        ssw_set_error("negative frame");
+        return -1;
+    }
+    if (frame < g->cache_frames) {
+        memcpy(senscr, g->cache.data() + (size_t)frame * h->n_sen, sizeof(int16_t) * h->n_sen);
+        return 0;
+    }
+    HIP_OK(hipSetDevice(m->device));
+    const int slot = frame % 2;
+    if (frame >= g->base.frame_idx) {
+        float row[SSW_MAX_FEAT * SSW_MAX_VECLEN];
+        for (int f = 0; f < h->n_feat; ++f)
+            memcpy(row + h->featoff[f], feat[f], sizeof(float) * h->veclen[f]);
+        HIP_OK(hipMemcpy(g->d_feat1, row, sizeof(float) * h->veclen_total, hipMemcpyHostToDevice));
+        ChainParams P;
+        fill_chain_params(m, P, g->d_feat1);
+        P.utt_off = g->d_utt1;
+        P.n_utts = 1;
+        P.carry_pk = g->d_hist_cw[slot ^ 1]; /* lastf, src/ptm_mgau.c:435-441 */
+        P.topn_cw = g->d_hist_cw[slot];
+        P.topn_sc = g->d_hist_sc[slot];
+        P.frame_base = frame;
+        hipLaunchKernelGGL((ptm_topn_chain_kernel<13, 2, 4, 0>), dim3((m->n_cbf + 3) / 4),
+                           dim3(256), 0, 0, P);
+        HIP_OK(hipGetLastError());
+    }
+    if (launch_senone(m, 1, g->d_hist_cw[slot], g->d_hist_sc[slot], g->d_out1, 0) < 0)
+        return -1;
+    HIP_OK(hipMemcpy(senscr, g->d_out1, sizeof(int16_t) * h->n_sen, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static int
+mgau_transform(ssw_mgau_t *mg, void *mllr)
+{
+    (void)mg;
+    (void)mllr;
+    ssw_set_error("MLLR transforms are outside the accelerated path");
+    return -1;
+}
+
+static void
+mgau_free(ssw_mgau_t *mg)
+{
+    ssw_mgau_impl *g = reinterpret_cast<ssw_mgau_impl *>(mg);
+    if (g == NULL)
+        return;
+    for (int i = 0; i < 2; ++i) {
+        (void)hipFree(g->d_hist_cw[i]);
+        (void)hipFree(g->d_hist_sc[i]);
+    }
+    (void)hipFree(g->d_utt1);
+    (void)hipFree(g->d_feat1);
+    (void)hipFree(g->d_out1);
+    delete g;
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* search-module shaped forced aligner                                                  */
+/* ---------------------------------------------------------------------------------- */
+struct ssw_state_align_search_s {
+    ssw_model_s *m;
+    ssw_mgau_impl *mgau;
+    int n_phones, n_frames, started, finished;
+    std::vector<uint16_t> senid;
+    std::vector<int16_t> tmatid;
+    std::vector<int32_t> sf, ef;
+    std::vector<ssw_align_entry_t> state0, states, phones;
+    std::vector<float> feats;
+};
+
+extern "C" ssw_state_align_search_t *
+ssw_state_align_search_init(ssw_model_t *m, ssw_mgau_t *mgau, int32_t n_phones,
+                            const int32_t *ssid, const int32_t *tmatid, const int32_t *start,
+                            const int32_t *duration)
+{
+    const ssw_host_model_t *h = m->h;
+    if (h->sseq == NULL || h->n_emit_state != 3) {
+        ssw_set_error("alignment needs a 3-state mdef");
+        return NULL;
+    }
+    if (n_phones < 1 || n_phones * 3 > 0xffff) { /* alignment vectors cap at 65535 entries */
+        ssw_set_error("bad phone count %d", n_phones);
+        return NULL;
+    }
+    ssw_state_align_search_s *s = new ssw_state_align_search_s();
+    s->m = m;
+    s->mgau = reinterpret_cast<ssw_mgau_impl *>(mgau);
+    s->n_phones = n_phones;
+    s->n_frames = 0;
+    s->started = s->finished = 0;
+    s->senid.resize((size_t)n_phones * 3);
+    s->tmatid.resize(n_phones);
+    s->sf.resize(n_phones);
+    s->ef.resize(n_phones);
+    s->state0.resize((size_t)n_phones * 3);
+    for (int p = 0; p < n_phones; ++p) {
+        if (ssid[p] < 0 || ssid[p] >= h->n_sseq) {
+            ssw_set_error("phone %d: senone sequence %d out of range", p, ssid[p]);
+            delete s;
+            return NULL;
+        }
+        for (int j = 0; j < 3; ++j) {
+            s->senid[(size_t)p * 3 + j] = h->sseq[(size_t)ssid[p] * 3 + j];
+            /* alignment_populate: states inherit the phone's window, score 0 */
+            s->state0[(size_t)p * 3 + j].start = start ? start[p] : 0;
+            s->state0[(size_t)p * 3 + j].duration = duration ? duration[p] : 0;
+            s->state0[(size_t)p * 3 + j].score = 0;
+        }
+        s->tmatid[p] = (int16_t)tmatid[p];
+        int st = start ? start[p] : 0, du = duration ? duration[p] : 0;
+        s->sf[p] = st > 0 ? st : 0;               /* state_align_search.c:464-467 */
+        s->ef[p] = du > 0 ? st + du : INT_MAX;    /* :468-471 */
+    }
+    return s;
+}
+
+extern "C" int
+ssw_state_align_search_start(ssw_state_align_search_t *s)
+{
+    s->n_frames = 0;
+    s->feats.clear();
+    s->started = 1;
+    s->finished = 0;
+    return 0;
+}
+
+extern "C" int
+ssw_state_align_search_step(ssw_state_align_search_t *s, const float *feat, int frame_idx)
+{
+    if (!s->started || frame_idx != s->n_frames) {
+        ssw_set_error("step(%d) out of order (next frame is %d)", frame_idx, s->n_frames);
+        return -1;
+    }
+    const int dim = s->m->h->veclen_total;
+    s->feats.insert(s->feats.end(), feat, feat + dim);
+    s->n_frames++;
+    return 0;
+}
+
+extern "C" int
+ssw_state_align_search_finish(ssw_state_align_search_t *s)
+{
+    ssw_model_s *m = s->m;
+    const ssw_host_model_t *h = m->h;
+    const int n = s->n_frames;
+    s->states = s->state0;
+    s->phones.assign(s->n_phones, ssw_align_entry_t{ 0, 0, 0 });
+    int16_t *d_scr = NULL;
+    float *d_feats = NULL;
+    int rv = -1, status = 0;
+    int32_t foff[2] = { 0, n }, poff[2] = { 0, s->n_phones };
+    std::vector<int32_t> parent((size_t)s->n_phones * 3);
+    if (hipSetDevice(m->device) != hipSuccess
+        || hipMalloc((void **)&d_scr, sizeof(int16_t) * (size_t)(n ? n : 1) * h->n_sen) != hipSuccess
+        || hipMalloc((void **)&d_feats, sizeof(float) * (size_t)(n ? n : 1) * h->veclen_total)
+            != hipSuccess) {
+        ssw_set_error("device allocation failed");
+        goto out;
+    }
+    if (n > 0) {
+        if (hipMemcpy(d_feats, s->feats.data(), sizeof(float) * s->feats.size(),
+                      hipMemcpyHostToDevice) != hipSuccess) {
+            ssw_set_error("feature upload failed");
+            goto out;
+        }
+        if (ssw_score_batch(m, s->mgau ? s->mgau->scorer : SSW_SCORER_PTM, d_feats, n, foff, 1,
+                            d_scr, NULL) < 0)
+            goto out;
+    }
+    if (ssw_align_batch(m, d_scr, 1, foff, poff, s->senid.data(), s->tmatid.data(), s->sf.data(),
+                        s->ef.data(), s->states.data(), &status, NULL) < 0)
+        goto out;
+    if (status != 0) {
+        if (status == -1)
+            ssw_set_error("Failed to reach final state in alignment");
+        else
+            ssw_set_error("Alignment failed in frame %d", -status - 2);
+        goto out;
+    }
+    for (size_t i = 0; i < parent.size(); ++i)
+        parent[i] = (int32_t)(i / 3);
+    if (ssw_alignment_propagate(s->states.data(), parent.data(), (int32_t)parent.size(),
+                                s->phones.data(), s->n_phones) < 0)
+        goto out;
+    s->finished = 1;
+    rv = 0;
+out:
+    (void)hipFree(d_scr);
+    (void)hipFree(d_feats);
+    return rv;
+}
+
+extern "C" int32_t
+ssw_state_align_search_n_frames(const ssw_state_align_search_t *s)
+{
+    return s->n_frames;
+}
+
+extern "C" const ssw_align_entry_t *
+ssw_state_align_search_states(const ssw_state_align_search_t *s, int32_t *n)
+{
+    if (n)
+        *n = (int32_t)s->states.size();
+    return s->states.data();
+}
+
+extern "C" const ssw_align_entry_t *
+ssw_state_align_search_phones(const ssw_state_align_search_t *s, int32_t *n)
+{
+    if (n)
+        *n = (int32_t)s->phones.size();
+    return s->phones.data();
+}
+
+extern "C" void
+ssw_state_align_search_free(ssw_state_align_search_t *s)
+{
+    delete s;
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* device-memory helpers                                                               */
+/* ---------------------------------------------------------------------------------- */
+extern "C" void *
+ssw_device_malloc(size_t nbytes)
+{
+    void *p = NULL;
+    if (hipMalloc(&p, nbytes ? nbytes : 1) != hipSuccess) {
+        ssw_set_error("hipMalloc(%zu) failed", nbytes);
+        return NULL;
+    }
+    return p;
+}
+
+extern "C" void
+ssw_device_free(void *d_ptr)
+{
+    (void)hipFree(d_ptr);
+}
+
+extern "C" int
+ssw_memcpy_h2d(void *d_dst, const void *src, size_t nbytes)
+{
+    HIP_OK(hipMemcpy(d_dst, src, nbytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int
+ssw_memcpy_d2h(void *dst, const void *d_src, size_t nbytes)
+{
+    HIP_OK(hipMemcpy(dst, d_src, nbytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int
+ssw_device_synchronize(void)
+{
+    HIP_OK(hipDeviceSynchronize());
+    return 0;
+}

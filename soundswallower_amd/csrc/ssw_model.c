@@ -1,0 +1,773 @@
+/*
+ * ssw_model.c -- host-side model loading for the MI355X acoustic path (plain C).
+ *
+ * Reads the Sphinx-3 binary model files and derives every table exactly as SoundSwallower
+ * derives it at load time (file:line citations are relative to the SoundSwallower tree):
+ *   s3 container, byte order, checksum   src/s3file.c:210-327, 366-445, 551-570
+ *   means / variances + precompute       src/ms_gauden.c:105-202, 217-258
+ *   sendump / mixture_weights            src/ptm_mgau.c:456-692, src/ms_senone.c:103-198
+ *   transition matrices                  src/tmat.c:125-227
+ *   binary mdef                          src/bin_mdef.c:333-540
+ *   integer log tables                   src/logmath.c:60-164, 282-301
+ * Load-time arithmetic is double precision libm (log, sqrt) followed by integer truncation,
+ * as in the reference; the results are data for the kernels.
+ */
+#include "ssw_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static __thread char tls_err[512];
+
+void
+ssw_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tls_err, sizeof(tls_err), fmt, ap);
+    va_end(ap);
+}
+
+const char *
+ssw_last_error(void)
+{
+    return tls_err;
+}
+
+int
+ssw_abi_version(void)
+{
+    return SSW_ABI_VERSION;
+}
+
+void
+ssw_config_defaults(ssw_config_t *cfg)
+{
+    cfg->logbase = 1.0001;
+    cfg->varfloor = 1e-4;
+    cfg->mixwfloor = 1e-7;
+    cfg->tmatfloor = 1e-4;
+    cfg->topn = 4;
+    cfg->ds = 1;
+    cfg->aw = 1;
+    cfg->device = -1;
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* Integer log domain (logmath_t).  Only what load time needs: log(), ln_to_log() at a  */
+/* given shift, and the 8-bit add table at shift 10.                                   */
+/* ---------------------------------------------------------------------------------- */
+typedef struct {
+    double inv_ln_base;
+    double base;
+} lbase_t;
+
+static int
+ilog(const lbase_t *b, int shift, double p)
+{
+    if (p <= 0)
+        return (int)((int32_t)0x80000000 >> (shift + 2)); /* logmath zero, logmath.c:84 */
+    return (int)(log(p) * b->inv_ln_base) >> shift;      /* logmath.c:288 */
+}
+
+static int
+iln_to_log(const lbase_t *b, int shift, double ln_p)
+{
+    return (int)(ln_p * b->inv_ln_base) >> shift; /* logmath.c:300 */
+}
+
+/* Add table for (base, shift): entry d = round(log_base(1 + base^-d')) >> shift for the first
+ * unshifted d' that lands in slot d (logmath.c:101-161).  Returns the entry count the
+ * reference would allocate (>= 256) or -1 when entries need more than 8 bits. */
+static int
+build_logadd8(const lbase_t *b, int shift, uint8_t out[256])
+{
+    uint32_t maxyx = (uint32_t)(log(2.0) / log(b->base) + 0.5) >> shift;
+    double byx = 1.0;
+    uint32_t i, size;
+    uint8_t seen[256];
+
+    if (maxyx >= 256)
+        return -1;
+    memset(out, 0, 256);
+    memset(seen, 0, sizeof(seen));
+    for (i = 0;; ++i) {
+        double lobyx = log(1.0 + byx) * b->inv_ln_base;
+        int32_t k = (int32_t)(lobyx + 0.5 * (1 << shift)) >> shift;
+        uint32_t slot = i >> shift;
+        /* the reference keeps a slot's first value and treats a stored 0 as "empty" */
+        if (slot < 256 && out[slot] == 0)
+            out[slot] = (uint8_t)k;
+        if (k <= 0)
+            break;
+        byx /= b->base;
+    }
+    size = (i >> shift);
+    if (size < 255)
+        size = 255;
+    (void)seen;
+    return (int)size + 1;
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* Byte cursor over a whole file                                                       */
+/* ---------------------------------------------------------------------------------- */
+typedef struct {
+    uint8_t *base;
+    size_t size, at;
+    int swap, summing;
+    uint32_t sum;
+    const char *name;
+} rd_t;
+
+static int
+rd_open(rd_t *r, const char *path)
+{
+    FILE *fp = fopen(path, "rb");
+    long sz;
+    memset(r, 0, sizeof(*r));
+    r->name = path;
+    if (fp == NULL) {
+        ssw_set_error("%s: cannot open", path);
+        return -1;
+    }
+    if (fseek(fp, 0, SEEK_END) != 0 || (sz = ftell(fp)) < 0) {
+        fclose(fp);
+        ssw_set_error("%s: cannot size", path);
+        return -1;
+    }
+    rewind(fp);
+    r->base = (uint8_t *)malloc(sz ? (size_t)sz : 1);
+    r->size = (size_t)sz;
+    if (r->base == NULL || fread(r->base, 1, r->size, fp) != r->size) {
+        fclose(fp);
+        free(r->base);
+        r->base = NULL;
+        ssw_set_error("%s: read failed", path);
+        return -1;
+    }
+    fclose(fp);
+    return 0;
+}
+
+static void
+rd_close(rd_t *r)
+{
+    free(r->base);
+    r->base = NULL;
+}
+
+static uint32_t
+flip32(uint32_t v)
+{
+    return ((v & 0xffu) << 24) | ((v & 0xff00u) << 8) | ((v >> 8) & 0xff00u) | (v >> 24);
+}
+
+/* n 32-bit words -> dst, honouring byte order and the rolling checksum
+ * (sum = rotl(sum, 20) + word, src/s3file.c:383-387) */
+static int
+rd_words(rd_t *r, void *dst, size_t n)
+{
+    uint32_t *w = (uint32_t *)dst;
+    size_t i;
+    if (r->size - r->at < 4 * n) {
+        ssw_set_error("%s: truncated (wanted %zu words at offset %zu)", r->name, n, r->at);
+        return -1;
+    }
+    memcpy(w, r->base + r->at, 4 * n);
+    r->at += 4 * n;
+    if (r->swap)
+        for (i = 0; i < n; ++i)
+            w[i] = flip32(w[i]);
+    if (r->summing) {
+        uint32_t s = r->sum;
+        for (i = 0; i < n; ++i)
+            s = ((s << 20) | (s >> 12)) + w[i];
+        r->sum = s;
+    }
+    return 0;
+}
+
+static int
+rd_i32(rd_t *r, int32_t *v)
+{
+    return rd_words(r, v, 1);
+}
+
+/* "s3\n" text header: `name value` lines up to `endhdr`, then the 0x11223344 marker.
+ * A `chksum0` line (any value) switches the trailing checksum on (src/s3file.c:289-290). */
+static int
+rd_s3_header(rd_t *r)
+{
+    int want_sum = 0;
+    uint32_t mark;
+    if (r->size < 3 || memcmp(r->base, "s3\n", 3) != 0) {
+        ssw_set_error("%s: missing s3 signature", r->name);
+        return -1;
+    }
+    r->at = 3;
+    for (;;) {
+        const char *line = (const char *)r->base + r->at;
+        const char *eol = memchr(line, '\n', r->size - r->at);
+        size_t len, a, z;
+        if (r->at >= r->size) {
+            ssw_set_error("%s: header runs off the end", r->name);
+            return -1;
+        }
+        len = eol ? (size_t)(eol - line) : r->size - r->at;
+        r->at += eol ? len + 1 : len;
+        for (a = 0; a < len && (line[a] == ' ' || line[a] == '\t' || line[a] == '\r'); ++a)
+            ;
+        for (z = a; z < len && !(line[z] == ' ' || line[z] == '\t' || line[z] == '\r'); ++z)
+            ;
+        if (z == a) {
+            ssw_set_error("%s: empty header line", r->name);
+            return -1;
+        }
+        if (line[a] == '#')
+            continue;
+        if (z - a <= 6 && memcmp(line + a, "endhdr", z - a) == 0)
+            break;
+        if (z - a == 7 && memcmp(line + a, "chksum0", 7) == 0)
+            want_sum = 1;
+    }
+    if (rd_words(r, &mark, 1) < 0)
+        return -1;
+    if (mark != 0x11223344u) {
+        if (flip32(mark) != 0x11223344u) {
+            ssw_set_error("%s: bad byte-order marker %08x", r->name, mark);
+            return -1;
+        }
+        r->swap = 1;
+    }
+    r->summing = want_sum;
+    r->sum = 0;
+    return 0;
+}
+
+static int
+rd_s3_finish(rd_t *r)
+{
+    uint32_t expect, got;
+    if (!r->summing)
+        return 0;
+    got = r->sum;
+    r->summing = 0;
+    if (rd_words(r, &expect, 1) < 0)
+        return -1;
+    if (expect != got) {
+        ssw_set_error("%s: checksum mismatch (file %08x, computed %08x)", r->name, expect, got);
+        return -1;
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* Gaussians                                                                           */
+/* ---------------------------------------------------------------------------------- */
+static float *
+read_gauss_file(const char *path, int32_t shape[3], int32_t veclen[SSW_MAX_FEAT])
+{
+    rd_t r;
+    int32_t total, per_density = 0, i;
+    float *data = NULL;
+
+    if (rd_open(&r, path) < 0)
+        return NULL;
+    if (rd_s3_header(&r) < 0 || rd_words(&r, shape, 3) < 0)
+        goto bad;
+    if (shape[1] < 1 || shape[1] > SSW_MAX_FEAT || shape[0] < 1 || shape[2] < 1) {
+        ssw_set_error("%s: unsupported shape %d x %d x %d", path, shape[0], shape[1], shape[2]);
+        goto bad;
+    }
+    if (rd_words(&r, veclen, (size_t)shape[1]) < 0 || rd_i32(&r, &total) < 0)
+        goto bad;
+    for (i = 0; i < shape[1]; ++i)
+        per_density += veclen[i];
+    if (total != shape[0] * shape[2] * per_density) {
+        ssw_set_error("%s: %d values do not match %d x %d x %d", path, total, shape[0],
+                      shape[2], per_density);
+        goto bad;
+    }
+    data = (float *)malloc(sizeof(float) * (size_t)total);
+    if (data == NULL || rd_words(&r, data, (size_t)total) < 0 || rd_s3_finish(&r) < 0)
+        goto bad;
+    rd_close(&r);
+    return data;
+bad:
+    free(data);
+    rd_close(&r);
+    return NULL;
+}
+
+static int
+load_gaussians(ssw_host_model_t *h, const lbase_t *lb, const char *means, const char *vars)
+{
+    int32_t sm[3], sv[3], vlv[SSW_MAX_FEAT], c, f, d, j;
+    const float vfloor = (float)h->cfg.varfloor; /* float32 parameter, ms_gauden.c:218 */
+    float *mp, *vp, *dp;
+
+    if ((h->mean = read_gauss_file(means, sm, h->veclen)) == NULL)
+        return -1;
+    if ((h->var = read_gauss_file(vars, sv, vlv)) == NULL)
+        return -1;
+    if (memcmp(sm, sv, sizeof(sm)) != 0 || memcmp(h->veclen, vlv, sizeof(int32_t) * sm[1])) {
+        ssw_set_error("means and variances have different shapes");
+        return -1;
+    }
+    h->n_cb = sm[0];
+    h->n_feat = sm[1];
+    h->n_density = sm[2];
+    for (f = 0, h->veclen_total = 0; f < h->n_feat; ++f) {
+        h->featoff[f] = h->veclen_total;
+        h->veclen_total += h->veclen[f];
+    }
+    h->det = (float *)malloc(sizeof(float) * (size_t)h->n_cb * h->n_feat * h->n_density);
+    if (h->det == NULL)
+        return -1;
+
+    /* Walk the file order once: per density, det = sum_j (float)ilog(1/sqrt(2 pi var_j))
+     * accumulated in float32; var_j <- (float)iln_to_log(1/(2 var_j)); floor first. */
+    mp = h->mean;
+    vp = h->var;
+    dp = h->det;
+    (void)mp;
+    for (c = 0; c < h->n_cb; ++c)
+        for (f = 0; f < h->n_feat; ++f)
+            for (d = 0; d < h->n_density; ++d) {
+                float acc = 0;
+                for (j = 0; j < h->veclen[f]; ++j, ++vp) {
+                    if (*vp < vfloor) {
+                        *vp = vfloor;
+                        h->n_floored++;
+                    }
+                    acc += (float)ilog(lb, 0, 1.0 / sqrt(*vp * 2.0 * M_PI));
+                    *vp = (float)iln_to_log(lb, 0, 1.0 / (*vp * 2.0));
+                }
+                *dp++ = acc;
+            }
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* Transition matrices                                                                 */
+/* ---------------------------------------------------------------------------------- */
+static void
+renorm(float *v, int n)
+{
+    double s = 0.0, k;
+    int i;
+    for (i = 0; i < n; ++i)
+        s += v[i];
+    if (s == 0.0)
+        return;
+    k = 1.0 / s;
+    for (i = 0; i < n; ++i)
+        v[i] = (float)(v[i] * k);
+}
+
+static int
+load_tmat(ssw_host_model_t *h, const lbase_t *lb, const char *path)
+{
+    rd_t r;
+    int32_t dims[4], t, i, k;
+    float row[16];
+
+    if (rd_open(&r, path) < 0)
+        return -1;
+    if (rd_s3_header(&r) < 0 || rd_words(&r, dims, 4) < 0)
+        goto bad;
+    if (dims[2] != dims[1] + 1 || dims[2] > 16 || dims[3] != dims[0] * dims[1] * dims[2]) {
+        ssw_set_error("%s: unsupported transition shape %d x %d x %d", path, dims[0], dims[1],
+                      dims[2]);
+        goto bad;
+    }
+    h->tp_n_tmat = dims[0];
+    h->tp_n_state = dims[1];
+    h->tp = (uint8_t *)malloc((size_t)dims[3]);
+    for (t = 0; t < dims[0]; ++t)
+        for (i = 0; i < dims[1]; ++i) {
+            if (rd_words(&r, row, (size_t)dims[2]) < 0)
+                goto bad;
+            renorm(row, dims[2]);
+            for (k = 0; k < dims[2]; ++k) /* floor only non-zero arcs, vector.c:116-123 */
+                if (row[k] != 0.0 && row[k] < h->cfg.tmatfloor)
+                    row[k] = (float)h->cfg.tmatfloor;
+            renorm(row, dims[2]);
+            for (k = 0; k < dims[2]; ++k) {
+                int q = (-ilog(lb, 0, row[k])) >> SSW_SENSCR_SHIFT; /* tmat.c:206 */
+                h->tp[((size_t)t * dims[1] + i) * dims[2] + k] = (uint8_t)(q > 255 ? 255 : q);
+            }
+        }
+    if (rd_s3_finish(&r) < 0)
+        goto bad;
+    rd_close(&r);
+    return 0;
+bad:
+    rd_close(&r);
+    return -1;
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* Binary model definition                                                             */
+/* ---------------------------------------------------------------------------------- */
+static uint32_t
+peek32(const rd_t *r, size_t at)
+{
+    uint32_t v;
+    memcpy(&v, r->base + at, 4);
+    return r->swap ? flip32(v) : v;
+}
+
+static uint16_t
+peek16(const rd_t *r, size_t at)
+{
+    uint16_t v;
+    memcpy(&v, r->base + at, 2);
+    return r->swap ? (uint16_t)((v << 8) | (v >> 8)) : v;
+}
+
+static int
+load_mdef(ssw_host_model_t *h, const char *path)
+{
+    rd_t r;
+    int32_t magic, ver, desc_len, hd[10], n_tree, i, j;
+    size_t names, at, phones, n_sseq_words;
+
+    if (rd_open(&r, path) < 0)
+        return -1;
+    if (rd_i32(&r, &magic) < 0)
+        goto bad;
+    if ((uint32_t)magic == 0x424d4446u)
+        r.swap = 1;
+    else if ((uint32_t)magic != 0x46444d42u) {
+        ssw_set_error("%s: not a BMDF file", path);
+        goto bad;
+    }
+    if (rd_i32(&r, &ver) < 0 || rd_i32(&r, &desc_len) < 0)
+        goto bad;
+    if (ver > 1 || desc_len < 0 || r.at + (size_t)desc_len > r.size) {
+        ssw_set_error("%s: unsupported BMDF version/descriptor", path);
+        goto bad;
+    }
+    r.at += (size_t)desc_len;
+    if (rd_words(&r, hd, 10) < 0)
+        goto bad;
+    h->n_ciphone = hd[0];
+    h->n_phone = hd[1];
+    h->n_emit_state = hd[2];
+    h->n_ci_sen = hd[3];
+    h->n_sen = hd[4];
+    h->n_tmat = hd[5];
+    h->n_sseq = hd[6];
+    n_tree = hd[8];
+    if (h->n_emit_state < 1) {
+        ssw_set_error("%s: mixed-topology mdef not supported", path);
+        goto bad;
+    }
+    /* CI names: n_ciphone NUL-terminated strings, block padded to 4 bytes */
+    names = at = r.at;
+    h->sil = -1;
+    for (i = 0; i < h->n_ciphone; ++i) {
+        const char *nm = (const char *)r.base + at;
+        size_t l = strnlen(nm, r.size - at);
+        if (at + l >= r.size)
+            goto trunc;
+        if (l == 3 && memcmp(nm, "SIL", 3) == 0)
+            h->sil = i;
+        at += l + 1;
+    }
+    at = names + ((at - names + 3) / 4) * 4;
+    phones = at + (size_t)n_tree * 8;
+    at = phones + (size_t)h->n_phone * 12;
+    if (at + 4 > r.size)
+        goto trunc;
+    n_sseq_words = peek32(&r, at);
+    at += 4;
+    if (at + 2 * n_sseq_words > r.size || n_sseq_words < (size_t)h->n_sseq * h->n_emit_state)
+        goto trunc;
+    h->sseq = (uint16_t *)malloc(2 * n_sseq_words);
+    for (i = 0; (size_t)i < n_sseq_words; ++i)
+        h->sseq[i] = peek16(&r, at + 2 * (size_t)i);
+
+    h->phone_ssid = (int32_t *)malloc(sizeof(int32_t) * (size_t)h->n_phone);
+    h->phone_tmat = (int32_t *)malloc(sizeof(int32_t) * (size_t)h->n_phone);
+    h->sen2cb = (int16_t *)malloc(sizeof(int16_t) * (size_t)h->n_sen);
+    for (i = 0; i < h->n_sen; ++i)
+        h->sen2cb[i] = -1;
+    for (i = 0; i < h->n_phone; ++i) {
+        size_t e = phones + (size_t)i * 12;
+        int base = (i < h->n_ciphone) ? i : r.base[e + 9]; /* first context byte = base phone */
+        h->phone_ssid[i] = (int32_t)peek32(&r, e);
+        h->phone_tmat[i] = (int32_t)peek32(&r, e + 4);
+        if (h->phone_ssid[i] < 0 || h->phone_ssid[i] >= h->n_sseq)
+            continue;
+        for (j = 0; j < h->n_emit_state; ++j) {
+            int s = h->sseq[(size_t)h->phone_ssid[i] * h->n_emit_state + j];
+            if (s < h->n_sen && h->sen2cb[s] < 0) /* first owner wins, bin_mdef.c:505-506 */
+                h->sen2cb[s] = (int16_t)base;
+        }
+    }
+    rd_close(&r);
+    return 0;
+trunc:
+    ssw_set_error("%s: truncated", path);
+bad:
+    rd_close(&r);
+    return -1;
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* Mixture weights                                                                     */
+/* ---------------------------------------------------------------------------------- */
+static int
+has_prefix(const uint8_t *s, size_t n, const char *key, int *val)
+{
+    size_t k = strlen(key);
+    if (n > k && memcmp(s, key, k) == 0) {
+        *val = atoi((const char *)s + k);
+        return 1;
+    }
+    return 0;
+}
+
+static int
+load_sendump(ssw_host_model_t *h, const char *path)
+{
+    rd_t r;
+    int32_t len, rows, cols;
+    int feats = h->n_feat, dens = h->n_density, sens = h->n_sen, clusters = 0, bits = 8, f, d, s;
+    uint8_t codebook[16];
+    size_t stride;
+
+    if (rd_open(&r, path) < 0)
+        return -1;
+    /* title: its length also reveals the byte order */
+    if (rd_i32(&r, &len) < 0)
+        goto bad;
+    if (len < 1 || len > 999) {
+        len = (int32_t)flip32((uint32_t)len);
+        if (len < 1 || len > 999) {
+            ssw_set_error("%s: implausible title length", path);
+            goto bad;
+        }
+        r.swap = 1;
+    }
+    if (r.at + (size_t)len > r.size || r.base[r.at + len - 1] != 0)
+        goto trunc;
+    r.at += (size_t)len;
+    /* header string */
+    if (rd_i32(&r, &len) < 0)
+        goto bad;
+    if (len < 1 || r.at + (size_t)len > r.size || r.base[r.at + len - 1] != 0)
+        goto trunc;
+    r.at += (size_t)len;
+    /* key/value strings, terminated by a zero length */
+    for (;;) {
+        if (rd_i32(&r, &len) < 0)
+            goto bad;
+        if (len == 0)
+            break;
+        if (len < 0 || r.at + (size_t)len > r.size)
+            goto trunc;
+        (void)(has_prefix(r.base + r.at, (size_t)len, "feature_count ", &feats)
+               || has_prefix(r.base + r.at, (size_t)len, "mixture_count ", &dens)
+               || has_prefix(r.base + r.at, (size_t)len, "model_count ", &sens)
+               || has_prefix(r.base + r.at, (size_t)len, "cluster_count ", &clusters)
+               || has_prefix(r.base + r.at, (size_t)len, "cluster_bits ", &bits));
+        r.at += (size_t)len;
+    }
+    rows = dens;
+    cols = sens;
+    if (clusters == 0 && (rd_i32(&r, &rows) < 0 || rd_i32(&r, &cols) < 0))
+        goto bad;
+    if (feats != h->n_feat || dens != h->n_density || sens != h->n_sen || rows != dens) {
+        ssw_set_error("%s: sendump is %d x %d x %d, model is %d x %d x %d", path, feats, dens,
+                      sens, h->n_feat, h->n_density, h->n_sen);
+        goto bad;
+    }
+    if ((clusters != 0 && clusters != 15 && clusters != 16) || (bits != 8 && bits != 4)) {
+        ssw_set_error("%s: unsupported cluster_count %d / cluster_bits %d", path, clusters, bits);
+        goto bad;
+    }
+    memset(codebook, 0, sizeof(codebook));
+    if (clusters) {
+        int n = clusters == 15 ? 16 : clusters; /* 15 is stored as 16, ptm_mgau.c:575-576 */
+        if (r.at + (size_t)n > r.size)
+            goto trunc;
+        memcpy(codebook, r.base + r.at, (size_t)n);
+        r.at += (size_t)n;
+    }
+    stride = bits == 4 ? ((size_t)cols + 1) / 2 : (size_t)cols;
+    if (r.at + stride * (size_t)rows * (size_t)feats > r.size)
+        goto trunc;
+    h->ptm_mixw = (uint8_t *)malloc((size_t)feats * dens * sens);
+    for (f = 0; f < feats; ++f)
+        for (d = 0; d < dens; ++d) {
+            const uint8_t *src = r.base + r.at + ((size_t)f * rows + d) * stride;
+            uint8_t *dst = h->ptm_mixw + ((size_t)f * dens + d) * sens;
+            if (!clusters) {
+                memcpy(dst, src, (size_t)sens);
+                continue;
+            }
+            /* Clustered dump, expanded once here with the reference's decode rule, which
+             * keys the nibble choice on the packed byte's own low bit (ptm_mgau.c:375-378). */
+            for (s = 0; s < sens; ++s) {
+                int packed = src[s / 2];
+                int code = (packed & 1) ? packed >> 4 : packed & 0x0f;
+                dst[s] = codebook[code];
+            }
+        }
+    rd_close(&r);
+    return 0;
+trunc:
+    ssw_set_error("%s: truncated", path);
+bad:
+    rd_close(&r);
+    return -1;
+}
+
+static int
+load_mixw(ssw_host_model_t *h, const lbase_t *lb, const char *path, int fill_ptm)
+{
+    rd_t r;
+    int32_t dims[4], s, f, c;
+    float *w = NULL;
+    const float wfloor = (float)h->cfg.mixwfloor;
+
+    if (rd_open(&r, path) < 0)
+        return -1;
+    if (rd_s3_header(&r) < 0 || rd_words(&r, dims, 4) < 0)
+        goto bad;
+    if (dims[1] != h->n_feat || dims[2] != h->n_density || dims[3] != dims[0] * dims[1] * dims[2]
+        || (h->n_sen && dims[0] != h->n_sen)) {
+        ssw_set_error("%s: mixture weights are %d x %d x %d, model wants %d x %d x %d", path,
+                      dims[0], dims[1], dims[2], h->n_sen, h->n_feat, h->n_density);
+        goto bad;
+    }
+    h->n_sen = dims[0];
+    w = (float *)malloc(sizeof(float) * (size_t)dims[2]);
+    h->ms_pdf = (uint8_t *)malloc((size_t)dims[3]);
+    if (fill_ptm)
+        h->ptm_mixw = (uint8_t *)malloc((size_t)dims[3]);
+    for (s = 0; s < dims[0]; ++s)
+        for (f = 0; f < dims[1]; ++f) {
+            if (rd_words(&r, w, (size_t)dims[2]) < 0)
+                goto bad;
+            renorm(w, dims[2]);
+            for (c = 0; c < dims[2]; ++c)
+                if (w[c] < (double)wfloor)
+                    w[c] = wfloor;
+            renorm(w, dims[2]);
+            for (c = 0; c < dims[2]; ++c) {
+                /* ms: shift-0 log, +511, >>10, saturate 255 (ms_senone.c:176-182) */
+                int p = -ilog(lb, 0, w[c]) + ((1 << (SSW_SENSCR_SHIFT - 1)) - 1);
+                h->ms_pdf[((size_t)s * dims[1] + f) * dims[2] + c]
+                    = (uint8_t)(p < (255 << SSW_SENSCR_SHIFT) ? p >> SSW_SENSCR_SHIFT : 255);
+                if (fill_ptm) { /* PTM: shift-10 log, saturate 159 (ptm_mgau.c:678-681) */
+                    int q = -ilog(lb, SSW_SENSCR_SHIFT, w[c]);
+                    if (q > SSW_MAX_NEG_MIXW || q < 0)
+                        q = SSW_MAX_NEG_MIXW;
+                    h->ptm_mixw[((size_t)f * dims[2] + c) * dims[0] + s] = (uint8_t)q;
+                }
+            }
+        }
+    if (rd_s3_finish(&r) < 0)
+        goto bad;
+    free(w);
+    rd_close(&r);
+    return 0;
+bad:
+    free(w);
+    rd_close(&r);
+    return -1;
+}
+
+/* ---------------------------------------------------------------------------------- */
+ssw_host_model_t *
+ssw_host_model_load(const char *mdef, const char *means, const char *variances,
+                    const char *sendump, const char *mixw, const char *tmat,
+                    const ssw_config_t *cfg)
+{
+    ssw_host_model_t *h = (ssw_host_model_t *)calloc(1, sizeof(*h));
+    lbase_t lb;
+    int i, n;
+
+    if (h == NULL)
+        return NULL;
+    if (cfg)
+        h->cfg = *cfg;
+    else
+        ssw_config_defaults(&h->cfg);
+    if (!(h->cfg.logbase > 1.0)) {
+        ssw_set_error("logbase must be > 1");
+        goto bad;
+    }
+    lb.base = h->cfg.logbase;
+    lb.inv_ln_base = 1.0 / log(h->cfg.logbase);
+    n = build_logadd8(&lb, SSW_SENSCR_SHIFT, h->logadd8);
+    if (n < 0) { /* same refusal as src/ptm_mgau.c:739-743 */
+        ssw_set_error("log base %f too small for an 8-bit add table", h->cfg.logbase);
+        goto bad;
+    }
+    h->logadd8_size = n;
+    h->zero8 = (int32_t)0x80000000 >> (SSW_SENSCR_SHIFT + 2);
+
+    if (means == NULL || variances == NULL) {
+        ssw_set_error("means and variances are required");
+        goto bad;
+    }
+    if (mdef && load_mdef(h, mdef) < 0)
+        goto bad;
+    if (load_gaussians(h, &lb, means, variances) < 0)
+        goto bad;
+    if (tmat && load_tmat(h, &lb, tmat) < 0)
+        goto bad;
+    if (sendump) {
+        if (h->n_sen == 0) {
+            ssw_set_error("a sendump needs the mdef for its senone count");
+            goto bad;
+        }
+        if (load_sendump(h, sendump) < 0)
+            goto bad;
+    }
+    if (mixw && load_mixw(h, &lb, mixw, sendump == NULL) < 0)
+        goto bad;
+    if (h->sen2cb == NULL && h->n_sen) {
+        ssw_set_error("senone to codebook map needs the mdef");
+        goto bad;
+    }
+    for (i = 0; i < h->n_sen; ++i)
+        if (h->sen2cb[i] < 0 || h->sen2cb[i] >= h->n_cb) {
+            /* PTM needs one codebook per CI phone (src/ptm_mgau.c:760-764) */
+            ssw_set_error("senone %d maps to codebook %d of %d", i, h->sen2cb[i], h->n_cb);
+            goto bad;
+        }
+    if (h->cfg.topn < 1 || h->cfg.topn > h->n_density)
+        h->cfg.topn = h->n_density;
+    return h;
+bad:
+    ssw_host_model_free(h);
+    return NULL;
+}
+
+void
+ssw_host_model_free(ssw_host_model_t *h)
+{
+    if (h == NULL)
+        return;
+    free(h->mean);
+    free(h->var);
+    free(h->det);
+    free(h->sseq);
+    free(h->sen2cb);
+    free(h->phone_ssid);
+    free(h->phone_tmat);
+    free(h->tp);
+    free(h->ptm_mixw);
+    free(h->ms_pdf);
+    free(h);
+}

@@ -1,0 +1,87 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MODEL_ROOT = os.path.join(ROOT, "soundswallower_amd", "model")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def _has_gpu():
+    return os.path.exists("/dev/kfd")
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def orc_en(oracle_mod):
+    return oracle_mod.Model(os.path.join(MODEL_ROOT, "en-us"))
+
+
+@pytest.fixture(scope="session")
+def orc_fr(oracle_mod):
+    return oracle_mod.Model(os.path.join(MODEL_ROOT, "fr-fr"))
+
+
+@pytest.fixture(scope="session")
+def gpu_en():
+    import soundswallower_amd as ssw
+    from soundswallower_amd import _lib
+    _lib.build()
+    return ssw.Model(os.path.join(MODEL_ROOT, "en-us"))
+
+
+@pytest.fixture(scope="session")
+def gpu_fr():
+    import soundswallower_amd as ssw
+    from soundswallower_amd import _lib
+    _lib.build()
+    return ssw.Model(os.path.join(MODEL_ROOT, "fr-fr"))
+
+
+def raw_means(model_dir):
+    """float32 means exactly as stored in the file, [cb][feat][density][veclen]."""
+    with open(os.path.join(model_dir, "means"), "rb") as fh:
+        blob = fh.read()
+    end = blob.index(b"endhdr\n") + len(b"endhdr\n")
+    hdr = np.frombuffer(blob, dtype="<u4", count=1, offset=end)
+    assert hdr[0] == 0x11223344
+    dims = np.frombuffer(blob, dtype="<i4", count=3, offset=end + 4)
+    n_cb, n_feat, n_den = (int(x) for x in dims)
+    vl = np.frombuffer(blob, dtype="<i4", count=n_feat, offset=end + 16)
+    n = int(np.frombuffer(blob, dtype="<i4", count=1, offset=end + 16 + 4 * n_feat)[0])
+    data = np.frombuffer(blob, dtype="<f4", count=n, offset=end + 20 + 4 * n_feat)
+    assert len(set(vl.tolist())) == 1
+    return data.reshape(n_cb, n_feat, n_den, int(vl[0])).copy()
+
+
+@pytest.fixture(scope="session")
+def means_en():
+    return raw_means(os.path.join(MODEL_ROOT, "en-us"))
+
+
+@pytest.fixture(scope="session")
+def means_fr():
+    return raw_means(os.path.join(MODEL_ROOT, "fr-fr"))
