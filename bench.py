@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- senone-frames/s of the PTM scoring hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path (ssw_score_batch: density/top-N kernel + senone kernel)
+over one batch of synthetic features already resident in HBM: BASELINE.json configs[1],
+4096 frames of 39-dim features as 16 utterances x 256 frames, en-us PTM model.  With N > 1
+(launched by torch.distributed.run, one rank per GPU) every rank scores its own shard of
+utterances -- the path partitions by utterance, there is no data-path collective -- and the
+reported value is the whole-job rate over the max-over-ranks time (weak scaling).
+
+Prints ONE JSON line on rank 0, including `roofline` (dominant kernel, HIP-event timed on the
+launch stream) and `cpu_baseline` (the CPU oracle timed on a bounded sample of the same
+workload on the host cores of this box).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_UTTS = 16
+UTT_FRAMES = 256
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, MI355X_MICROARCH.md
+VALU_PEAK_OPS = 78.6e12        # non-fused fp32 lane-ops/s: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+
+
+def algorithmic_bytes(n_sen, n_feat, topn, n_cb, n_density, veclen_total, batch):
+    """SURVEY.md 8(d) touched-bytes accounting, per frame, and its split over the two kernels."""
+    feat_b = 4 * veclen_total
+    out_b = 2 * n_sen
+    mixw_b = n_sen * n_feat * topn
+    gauss_block = n_cb * n_density * (2 * veclen_total + n_feat) * 4
+    topn_b = n_cb * n_feat * (topn + 4 * topn)          # packed cw + int32 scores between kernels
+    whole = feat_b + out_b + mixw_b + gauss_block / batch
+    return {"path": whole,
+            "topn_kernel": feat_b + gauss_block / batch + topn_b,
+            "senone_kernel": topn_b + mixw_b + out_b}
+
+
+def cpu_baseline(model_dir, feats, utt_off, target_s=12.0):
+    """Time the CPU oracle (scalar C restatement of the reference path) on a bounded sample."""
+    from oracle import oracle as O
+    m = O.Model(model_dir)
+    n_done, t0 = 0, time.perf_counter()
+    u = 0
+    while u < len(utt_off) - 1:
+        m.ptm_score_utt(feats[utt_off[u]:utt_off[u + 1]])
+        n_done += int(utt_off[u + 1] - utt_off[u])
+        u += 1
+        if time.perf_counter() - t0 > target_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n_done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{u} of {len(utt_off) - 1} utterances x {UTT_FRAMES} frames of the bench "
+                      f"batch ({n_done} frames, {dt:.1f} s, 1 thread of the CPU oracle)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--model", default="en-us")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the scoring path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import soundswallower_amd as ssw
+    from soundswallower_amd import _lib
+    from soundswallower_amd.parallel import shard_utterances
+    from soundswallower_amd.synth import read_raw_means as raw_means
+
+    _lib.build()
+    mdir = ssw.model_dir(args.model)
+    model = ssw.Model(mdir, config={"device": local_rank})
+    means = raw_means(mdir)
+
+    # this rank's shard of the global utterance list (weak scaling: N_UTTS per rank)
+    global_utts = list(range(N_UTTS * world))
+    mine = shard_utterances([UTT_FRAMES] * len(global_utts), world)[rank]
+    feats = np.concatenate([ssw.synth_features(means, UTT_FRAMES, 12345 + u) for u in mine])
+    utt_off = (np.arange(len(mine) + 1) * UTT_FRAMES).astype(np.int32)
+    n_frames = feats.shape[0]
+
+    d_feats = torch.from_numpy(feats).cuda()
+    d_out = torch.empty((n_frames, model.n_sen), dtype=torch.int16, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        model.score_batch_device(d_feats, n_frames, utt_off, d_out, stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel durations from HIP events recorded on the same stream, same steps again
+    model.set_kernel_timing(True)
+    k_ms = np.zeros(2)
+    n_prof = max(1, min(args.steps, 50))
+    for _ in range(n_prof):
+        step()
+        k_ms += np.array(model.kernel_timing())
+    model.set_kernel_timing(False)
+    k_ms /= n_prof
+
+    if rank != 0:
+        if dist:
+            dist.destroy_process_group()
+        return
+
+    ab = algorithmic_bytes(model.n_sen, model.n_feat, model.topn, model.n_cb, model.n_density,
+                           model.veclen_total, n_frames)
+    names = ("topn_kernel", "senone_kernel")
+    dom = int(np.argmax(k_ms))
+    achieved = ab[names[dom]] * n_frames / (k_ms[dom] * 1e-3) / 1e9
+    total_frames = n_frames * world * args.steps
+    fps = total_frames / elapsed
+    ops_per_frame = model.n_cb * model.n_feat * (model.n_density + model.topn) * 13 * 4
+    flagged, pairs = model.last_stats()
+    out = {
+        "metric": "senone-frames/sec (en-us PTM)",
+        "value": fps,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32+i32",
+        "data": "synthetic",
+        "config": {"workload": f"PTM senone scoring, {args.model}, {N_UTTS} utterances x "
+                               f"{UTT_FRAMES} frames = {n_frames} frames per GPU per step, "
+                               f"39-dim features resident in HBM, compallsen=yes, topn=4",
+                   "n_sen": model.n_sen, "n_cb": model.n_cb, "parallelism": f"utt-shard x{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": names[dom], "kernel_ms": float(k_ms[dom]),
+                     "algorithmic_bytes_per_frame": ab[names[dom]]},
+        "kernels_ms": {"topn_kernel": float(k_ms[0]), "senone_kernel": float(k_ms[1])},
+        "path_algorithmic_bytes_per_frame": ab["path"],
+        "path_hbm_frac": fps / world * ab["path"] / (HBM_PEAK_GBS * 1e9),
+        "valu_frac": fps / world * ops_per_frame / VALU_PEAK_OPS,
+        "exact_pass_share": flagged / max(pairs, 1),
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(mdir, feats, utt_off)
+    print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

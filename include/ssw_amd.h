@@ -102,6 +102,13 @@ int ssw_score_batch_topn(ssw_model_t *m, int32_t n_frames, uint8_t *cw, int32_t 
  * prove order-independent and handed to the exact sequential pass, [1] = pairs total. */
 int ssw_score_batch_stats(ssw_model_t *m, int64_t stats[2]);
 
+/* Per-kernel timing with HIP events recorded on the launch stream (for bench.py's roofline
+ * line).  When enabled every ssw_score_batch call brackets each kernel with events;
+ * ssw_get_kernel_timing synchronises and returns the last call's milliseconds:
+ * ms[0] = top-N (density) kernel(s), ms[1] = senone kernel.  Returns the number written. */
+int ssw_set_kernel_timing(ssw_model_t *m, int enable);
+int ssw_get_kernel_timing(ssw_model_t *m, float *ms, int n);
+
 /* ------------------------------------------------------------------------------------ */
 /* Scorer object: drop-in for mgau_t / mgaufuncs_t (include/soundswallower/acmod.h:93-111).*/
 /* The first two members mirror mgau_t so acmod can write frame_idx                       */

@@ -134,6 +134,15 @@ class Model:
         assert cw.size == n_frames * n_cbf * self.topn
         return cw, sc
 
+    def set_kernel_timing(self, enable=True):
+        _check(self._L.ssw_set_kernel_timing(self._m, int(bool(enable))), "ssw_set_kernel_timing")
+
+    def kernel_timing(self):
+        """(topn_ms, senone_ms) of the last score_batch call, from HIP events on its stream."""
+        ms = np.zeros(2, np.float32)
+        _check(self._L.ssw_get_kernel_timing(self._m, _ptr(ms), 2), "ssw_get_kernel_timing")
+        return float(ms[0]), float(ms[1])
+
     def last_stats(self):
         st = np.zeros(2, np.int64)
         self._L.ssw_score_batch_stats(self._m, _ptr(st))

@@ -770,6 +770,9 @@ struct ssw_model_s {
     size_t ws_frames, ws_utts;
     int last_n_frames;
     int64_t stats[2];
+    /* optional per-kernel event timing */
+    int timing;
+    hipEvent_t ev[3];
     /* host-API staging */
     float *d_feats;
     int16_t *d_out;
@@ -887,6 +890,9 @@ ssw_model_free(ssw_model_t *m)
     (void)hipFree(m->d_utt_off);
     (void)hipFree(m->d_feats);
     (void)hipFree(m->d_out);
+    if (m->timing)
+        for (int i = 0; i < 3; ++i)
+            (void)hipEventDestroy(m->ev[i]);
     ssw_host_model_free(m->h);
     delete m;
 }
@@ -1073,11 +1079,17 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
     fill_chain_params(m, P, d_feats);
     P.n_utts = n_utts;
     int n_chain = n_utts * m->n_cbf;
+    if (m->timing)
+        HIP_OK(hipEventRecord(m->ev[0], st));
     hipLaunchKernelGGL((ptm_topn_chain_kernel<13, 2, 4, 0>), dim3((n_chain + 3) / 4), dim3(256),
                        0, st, P);
     HIP_OK(hipGetLastError());
+    if (m->timing)
+        HIP_OK(hipEventRecord(m->ev[1], st));
     if (launch_senone(m, n_frames, m->d_topn_cw, m->d_topn_sc, d_out, st) < 0)
         return -1;
+    if (m->timing)
+        HIP_OK(hipEventRecord(m->ev[2], st));
     m->last_n_frames = n_frames;
     m->stats[0] = (int64_t)n_frames * m->n_cbf;
     m->stats[1] = (int64_t)n_frames * m->n_cbf;
@@ -1125,6 +1137,36 @@ ssw_score_batch_topn(ssw_model_t *m, int32_t n_frames, uint8_t *cw, int32_t *sco
     HIP_OK(hipMemcpy(score, m->d_topn_sc, (size_t)n_frames * m->n_cbf * 16,
                      hipMemcpyDeviceToHost));
     return 0;
+}
+
+extern "C" int
+ssw_set_kernel_timing(ssw_model_t *m, int enable)
+{
+    HIP_OK(hipSetDevice(m->device));
+    if (enable && !m->timing) {
+        for (int i = 0; i < 3; ++i)
+            HIP_OK(hipEventCreate(&m->ev[i]));
+        m->timing = 1;
+    } else if (!enable && m->timing) {
+        for (int i = 0; i < 3; ++i)
+            (void)hipEventDestroy(m->ev[i]);
+        m->timing = 0;
+    }
+    return 0;
+}
+
+extern "C" int
+ssw_get_kernel_timing(ssw_model_t *m, float *ms, int n)
+{
+    if (!m->timing) {
+        ssw_set_error("kernel timing is off");
+        return -1;
+    }
+    HIP_OK(hipEventSynchronize(m->ev[2]));
+    int k = 0;
+    for (; k < 2 && k < n; ++k)
+        HIP_OK(hipEventElapsedTime(&ms[k], m->ev[k], m->ev[k + 1]));
+    return k;
 }
 
 extern "C" int

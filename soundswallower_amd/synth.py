@@ -62,3 +62,22 @@ def synth_alignment_task(sseq: np.ndarray, phone_ssid: np.ndarray, phone_tmat: n
     tmat = phone_tmat[pid].astype(np.int16)
     senid = sseq[ssid].astype(np.uint16)
     return senid, tmat, ssid
+
+
+def read_raw_means(model_dir: str) -> np.ndarray:
+    """float32 means exactly as stored in the s3 file: [cb][feat][density][veclen]
+    (equal stream lengths only).  Input to synth_features on both the oracle and GPU sides."""
+    import os
+    with open(os.path.join(model_dir, "means"), "rb") as fh:
+        blob = fh.read()
+    end = blob.index(b"endhdr\n") + len(b"endhdr\n")
+    magic = np.frombuffer(blob, dtype="<u4", count=1, offset=end)[0]
+    bo = "<" if magic == 0x11223344 else ">"
+    dims = np.frombuffer(blob, dtype=bo + "i4", count=3, offset=end + 4)
+    n_cb, n_feat, n_den = (int(x) for x in dims)
+    vl = np.frombuffer(blob, dtype=bo + "i4", count=n_feat, offset=end + 16)
+    n = int(np.frombuffer(blob, dtype=bo + "i4", count=1, offset=end + 16 + 4 * n_feat)[0])
+    data = np.frombuffer(blob, dtype=bo + "f4", count=n, offset=end + 20 + 4 * n_feat)
+    if len(set(vl.tolist())) != 1:
+        raise ValueError("streams of different lengths")
+    return data.reshape(n_cb, n_feat, n_den, int(vl[0])).astype(np.float32)

@@ -61,20 +61,7 @@ def gpu_fr():
     return ssw.Model(os.path.join(MODEL_ROOT, "fr-fr"))
 
 
-def raw_means(model_dir):
-    """float32 means exactly as stored in the file, [cb][feat][density][veclen]."""
-    with open(os.path.join(model_dir, "means"), "rb") as fh:
-        blob = fh.read()
-    end = blob.index(b"endhdr\n") + len(b"endhdr\n")
-    hdr = np.frombuffer(blob, dtype="<u4", count=1, offset=end)
-    assert hdr[0] == 0x11223344
-    dims = np.frombuffer(blob, dtype="<i4", count=3, offset=end + 4)
-    n_cb, n_feat, n_den = (int(x) for x in dims)
-    vl = np.frombuffer(blob, dtype="<i4", count=n_feat, offset=end + 16)
-    n = int(np.frombuffer(blob, dtype="<i4", count=1, offset=end + 16 + 4 * n_feat)[0])
-    data = np.frombuffer(blob, dtype="<f4", count=n, offset=end + 20 + 4 * n_feat)
-    assert len(set(vl.tolist())) == 1
-    return data.reshape(n_cb, n_feat, n_den, int(vl[0])).copy()
+from soundswallower_amd.synth import read_raw_means as raw_means  # noqa: E402
 
 
 @pytest.fixture(scope="session")
