@@ -246,32 +246,51 @@ load_lane_gaussians(const float *rec_cbf, int lane, float (&mean)[NDL][VECLEN],
     }
 }
 
-/* MODE 0: one wave per (utterance, cbf) chain, all frames in order, history reset (or taken
- *         from `carry_pk`).
- * MODE 1: fix-up: one wave per work item = head of a run of flagged frames of one chain; the
- *         carried order comes from the previous frame's final result in topn_cw. */
-template <int VECLEN, int NDL, int TOPN, int MODE>
+/* Densities of one frame for the wave's 64*NDL codewords, then one exact top-N step, then the
+ * frame's packed result is stored by lane 0. */
+template <int VECLEN, int NDL, int TOPN>
+__device__ __forceinline__ void
+chain_frame(const ChainParams &P, int t, int cbf, int f, bool do_scan, int lane,
+            const float (&mean)[NDL][VECLEN], const float (&var)[NDL][VECLEN],
+            const float (&det)[NDL], int (&Lc)[TOPN], int (&Ls)[TOPN])
+{
+    const float *xp = P.feats + (size_t)t * P.featdim + P.featoff[f];
+    float x[VECLEN];
+#pragma unroll
+    for (int j = 0; j < VECLEN; ++j)
+        x[j] = xp[j];
+    float dv[NDL];
+    int iv[NDL];
+#pragma unroll
+    for (int h = 0; h < NDL; ++h) {
+        dv[h] = density<VECLEN>(x, mean[h], var[h], det[h]);
+        iv[h] = dens2int(dv[h]);
+    }
+    topn_exact_step<NDL, TOPN>(dv, iv, Lc, Ls, do_scan);
+    if (lane == 0) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int k = 0; k < TOPN; ++k)
+            pk |= (uint32_t)(Lc[k] & 0xff) << (8 * k);
+        P.topn_cw[(size_t)t * P.n_cbf + cbf] = pk;
+        static_assert(TOPN == 4, "score store is an int4");
+        P.topn_sc[(size_t)t * P.n_cbf + cbf] = make_int4(Ls[0], Ls[1], Ls[2], Ls[3]);
+    }
+}
+
+/* Exact path: one wave per (utterance, cbf) chain, all frames in order, history reset (or
+ * taken from `carry_pk`).  Used when ds != 1 and by the one-frame frame_eval path. */
+template <int VECLEN, int NDL, int TOPN>
 __global__ void __launch_bounds__(256)
 ptm_topn_chain_kernel(ChainParams P)
 {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    int cbf, t0, t1, u = 0;
-    if (MODE == 0) {
-        if (wid >= P.n_utts * P.n_cbf)
-            return;
-        u = wid / P.n_cbf;
-        cbf = wid - u * P.n_cbf;
-        t0 = P.utt_off[u];
-        t1 = P.utt_off[u + 1];
-    } else {
-        if (wid >= P.n_work)
-            return;
-        int item = P.work[wid];
-        cbf = item & 0xff;
-        t0 = item >> 8;
-        t1 = P.n_frames; /* run ends at the first unflagged frame, checked below */
-    }
+    if (wid >= P.n_utts * P.n_cbf)
+        return;
+    const int u = wid / P.n_cbf;
+    const int cbf = wid - u * P.n_cbf;
+    const int t0 = P.utt_off[u], t1 = P.utt_off[u + 1];
     const int f = cbf % P.n_feat;
     const float *rec_cbf = P.rec + (size_t)cbf * (NDL * 64) * SSW_REC_FLOATS;
 
@@ -279,15 +298,7 @@ ptm_topn_chain_kernel(ChainParams P)
     load_lane_gaussians<VECLEN, NDL>(rec_cbf, lane, mean, var, det);
 
     int Lc[TOPN], Ls[TOPN];
-    int ustart = t0;
-    if (MODE == 1)
-        ustart = P.frame_utt_start[t0];
-    if (MODE == 1 && t0 > ustart) {
-        uint32_t pk = P.topn_cw[(size_t)(t0 - 1) * P.n_cbf + cbf];
-#pragma unroll
-        for (int k = 0; k < TOPN; ++k)
-            Lc[k] = (pk >> (8 * k)) & 0xff;
-    } else if (MODE == 0 && P.carry_pk != nullptr) {
+    if (P.carry_pk != nullptr) {
         uint32_t pk = P.carry_pk[(size_t)u * P.n_cbf + cbf];
 #pragma unroll
         for (int k = 0; k < TOPN; ++k)
@@ -300,38 +311,253 @@ ptm_topn_chain_kernel(ChainParams P)
 #pragma unroll
     for (int k = 0; k < TOPN; ++k)
         Ls[k] = INT_MIN;
-
     for (int t = t0; t < t1; ++t) {
-        if (MODE == 1) {
-            /* stop at the end of this run of flagged frames (never cross an utterance start:
-             * frame_utt_start changes there and the next head owns it) */
-            size_t bit = (size_t)t * P.n_cbf + cbf;
-            bool flagged = (P.flags[bit >> 5] >> (bit & 31)) & 1u;
-            if (t > t0 && (!flagged || P.frame_utt_start[t] != ustart))
-                break;
+        bool do_scan = ((t - t0 + P.frame_base) % P.ds) == 0; /* src/ptm_mgau.c:241 */
+        chain_frame<VECLEN, NDL, TOPN>(P, t, cbf, f, do_scan, lane, mean, var, det, Lc, Ls);
+    }
+}
+
+/* Fix-up pass behind ptm_topn_frames_kernel: a persistent grid of waves sweeps the flag bitset
+ * (bit t*n_cbf + cbf = "the history-free result of this (frame, chain) pair is not proven
+ * order-independent").  The head of every run of consecutive flagged frames of a chain is
+ * re-done exactly: carried order = the previous frame's (final) result, or the reset state at
+ * an utterance start; the run is walked in frame order.  ds == 1 only. */
+template <int VECLEN, int NDL, int TOPN>
+__global__ void __launch_bounds__(64)
+ptm_topn_fixup_kernel(ChainParams P, int n_words, unsigned long long *n_fixed)
+{
+    const int lane = threadIdx.x;
+    float mean[NDL][VECLEN], var[NDL][VECLEN], det[NDL];
+    int loaded_cbf = -1;
+    unsigned long long fixed = 0;
+    for (int chunk = blockIdx.x; chunk * 64 < n_words; chunk += gridDim.x) {
+        int widx = chunk * 64 + lane;
+        uint32_t word = widx < n_words ? P.flags[widx] : 0u;
+        unsigned long long wmask = __ballot(word != 0);
+        while (wmask) {
+            int l = __builtin_ctzll(wmask);
+            wmask &= wmask - 1;
+            uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)word, l);
+            while (w) {
+                int b = __builtin_ctz(w);
+                w &= w - 1;
+                long long bit = ((long long)(chunk * 64 + l) << 5) + b;
+                int t = (int)(bit / P.n_cbf);
+                int cbf = (int)(bit - (long long)t * P.n_cbf);
+                /* utterance of frame t: last u with utt_off[u] <= t */
+                int lo = 0, hi = P.n_utts;
+                while (hi - lo > 1) {
+                    int mid = (lo + hi) >> 1;
+                    if (P.utt_off[mid] <= t)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                const int ustart = P.utt_off[lo], uend = P.utt_off[lo + 1];
+                if (t > ustart) { /* only run heads start a walk */
+                    long long pbit = bit - P.n_cbf;
+                    if ((P.flags[pbit >> 5] >> (pbit & 31)) & 1u)
+                        continue;
+                }
+                if (cbf != loaded_cbf) {
+                    load_lane_gaussians<VECLEN, NDL>(
+                        P.rec + (size_t)cbf * (NDL * 64) * SSW_REC_FLOATS, lane, mean, var, det);
+                    loaded_cbf = cbf;
+                }
+                int Lc[TOPN], Ls[TOPN];
+                if (t > ustart) {
+                    uint32_t pk = P.topn_cw[(size_t)(t - 1) * P.n_cbf + cbf];
+#pragma unroll
+                    for (int k = 0; k < TOPN; ++k)
+                        Lc[k] = (pk >> (8 * k)) & 0xff;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < TOPN; ++k)
+                        Lc[k] = k;
+                }
+#pragma unroll
+                for (int k = 0; k < TOPN; ++k)
+                    Ls[k] = INT_MIN;
+                const int f = cbf % P.n_feat;
+                for (int tt = t; tt < uend; ++tt) {
+                    if (tt > t) {
+                        long long nb = (long long)tt * P.n_cbf + cbf;
+                        if (!((P.flags[nb >> 5] >> (nb & 31)) & 1u))
+                            break;
+                    }
+                    chain_frame<VECLEN, NDL, TOPN>(P, tt, cbf, f, true, lane, mean, var, det, Lc,
+                                                   Ls);
+                    ++fixed;
+                }
+            }
         }
-        const float *xp = P.feats + (size_t)t * P.featdim + P.featoff[f];
-        float x[VECLEN];
+    }
+    if (lane == 0 && fixed)
+        atomicAdd(n_fixed, fixed);
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* K1a fast path: history-free top-N, one lane per frame                                 */
+/* ---------------------------------------------------------------------------------- */
+/*
+ * The reference's top-N list depends on the previous frame only through tie order and
+ * boundary membership among EQUAL truncated scores.  If the four best
+ * densities of a frame truncate to four distinct ints, all greater than the int of every other
+ * density, the reference's list is exactly "the four best, best first" whatever it carried in
+ * (proof in DESIGN.md).  So every (frame, chain) pair is first evaluated independently:
+ *
+ *   - a wave owns one (codebook, stream) and 64*FPL frames, one frame per lane (FPL packed);
+ *     the 128 Gaussians stream through SGPRs (wave-uniform scalar loads), the lane's feature
+ *     vector stays in VGPRs; the four fp32 ops per dimension run as packed v_pk_* ops over
+ *     the lane's FPL frames, each op rounded on its own, in the reference's order;
+ *   - a running top-5 is kept as 5 floats per frame whose low 7 mantissa bits carry the
+ *     codeword (v_and_or + 5 x v_med3): 6 VALU ops per density, no cross-lane traffic;
+ *   - the 4 best codewords are then recomputed exactly (gather of 4 records) and sorted; the
+ *     5th key bounds every other density from above.  When "4 distinct ints > bound" cannot
+ *     be shown the pair is flagged and ptm_topn_fixup_kernel redoes it with the exact
+ *     sequential state machine.
+ */
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+struct FramesParams {
+    uint32_t *topn_cw;
+    int4 *topn_sc;
+    uint32_t *flags;
+    int n_frames, n_cbf, n_feat, featdim;
+    int featoff[SSW_MAX_FEAT];
+};
+
+__device__ __forceinline__ float
+med3f(float a, float b, float c)
+{
+    return __builtin_amdgcn_fmed3f(a, b, c);
+}
+
+template <int VECLEN, int FPL>
+__global__ void __launch_bounds__(256)
+ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ feats,
+                       FramesParams P)
+{
+    static_assert(FPL == 1 || FPL == 2, "one or two frames per lane");
+    const int lane = threadIdx.x & 63;
+    const int cbf = blockIdx.y;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int t_base = tile * 64 * FPL;
+    if (t_base >= P.n_frames)
+        return;
+    const int f = cbf % P.n_feat;
+    const float *rec_cbf = rec + (size_t)cbf * 128 * SSW_REC_FLOATS;
+
+    int tt[FPL];
+    float x[FPL][VECLEN];
+#pragma unroll
+    for (int h = 0; h < FPL; ++h) {
+        tt[h] = t_base + h * 64 + lane;
+        int tl = tt[h] < P.n_frames ? tt[h] : P.n_frames - 1;
+        const float *xp = feats + (size_t)tl * P.featdim + P.featoff[f];
 #pragma unroll
         for (int j = 0; j < VECLEN; ++j)
-            x[j] = xp[j];
-        float dv[NDL];
-        int iv[NDL];
+            x[h][j] = xp[j];
+    }
+
+    const float NEG_INF = -__builtin_huge_valf(), POS_INF = __builtin_huge_valf();
+    float L[FPL][5];
 #pragma unroll
-        for (int h = 0; h < NDL; ++h) {
-            dv[h] = density<VECLEN>(x, mean[h], var[h], det[h]);
-            iv[h] = dens2int(dv[h]);
+    for (int h = 0; h < FPL; ++h)
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            L[h][k] = NEG_INF;
+
+    for (int cw = 0; cw < 128; ++cw) {
+        const float *r = rec_cbf + cw * SSW_REC_FLOATS; /* wave-uniform: scalar loads */
+        float d[FPL];
+        if (FPL == 2) {
+            float2v dd = { r[SSW_REC_DET], r[SSW_REC_DET] };
+#pragma unroll
+            for (int j = 0; j < VECLEN; ++j) {
+                float2v xx = { x[0][j], x[FPL - 1][j] };
+                float2v mm = { r[j], r[j] };
+                float2v vv = { r[SSW_REC_VAR + j], r[SSW_REC_VAR + j] };
+                float2v diff = xx - mm;
+                float2v sq = diff * diff;
+                float2v c = sq * vv;
+                dd = dd - c;
+            }
+            d[0] = dd.x;
+            d[FPL - 1] = dd.y;
+        } else {
+            float dd = r[SSW_REC_DET];
+#pragma unroll
+            for (int j = 0; j < VECLEN; ++j) {
+                float diff = x[0][j] - r[j];
+                float sq = diff * diff;
+                float c = sq * r[SSW_REC_VAR + j];
+                dd = dd - c;
+            }
+            d[0] = dd;
         }
-        bool do_scan = ((t - ustart + P.frame_base) % P.ds) == 0; /* src/ptm_mgau.c:241 */
-        topn_exact_step<NDL, TOPN>(dv, iv, Lc, Ls, do_scan);
-        if (lane == 0) {
-            uint32_t pk = 0;
 #pragma unroll
-            for (int k = 0; k < TOPN; ++k)
-                pk |= (uint32_t)(Lc[k] & 0xff) << (8 * k);
-            P.topn_cw[(size_t)t * P.n_cbf + cbf] = pk;
-            static_assert(TOPN == 4, "score store is an int4");
-            P.topn_sc[(size_t)t * P.n_cbf + cbf] = make_int4(Ls[0], Ls[1], Ls[2], Ls[3]);
+        for (int h = 0; h < FPL; ++h) {
+            float key = __uint_as_float((__float_as_uint(d[h]) & ~127u) | (uint32_t)cw);
+            L[h][4] = med3f(L[h][3], L[h][4], key);
+            L[h][3] = med3f(L[h][2], L[h][3], key);
+            L[h][2] = med3f(L[h][1], L[h][2], key);
+            L[h][1] = med3f(L[h][0], L[h][1], key);
+            L[h][0] = med3f(L[h][0], POS_INF, key);
+        }
+    }
+
+#pragma unroll
+    for (int h = 0; h < FPL; ++h) {
+        int c[4], s[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c[k] = (int)(__float_as_uint(L[h][k]) & 127u);
+            const float4 *rp = reinterpret_cast<const float4 *>(rec_cbf + c[k] * SSW_REC_FLOATS);
+            float buf[SSW_REC_FLOATS];
+#pragma unroll
+            for (int q = 0; q < SSW_REC_FLOATS / 4; ++q) {
+                float4 v = rp[q];
+                buf[q * 4 + 0] = v.x;
+                buf[q * 4 + 1] = v.y;
+                buf[q * 4 + 2] = v.z;
+                buf[q * 4 + 3] = v.w;
+            }
+            float dd = buf[SSW_REC_DET];
+#pragma unroll
+            for (int j = 0; j < VECLEN; ++j) {
+                float diff = x[h][j] - buf[j];
+                float sq = diff * diff;
+                float cc = sq * buf[SSW_REC_VAR + j];
+                dd = dd - cc;
+            }
+            s[k] = dens2int(dd);
+        }
+        /* sort the four (score, cw) pairs, best first */
+#define CSWAP(a, b)                                                                          \
+    {                                                                                        \
+        bool sw = s[b] > s[a];                                                               \
+        int ts = sw ? s[b] : s[a], tc = sw ? c[b] : c[a];                                    \
+        s[b] = sw ? s[a] : s[b];                                                             \
+        c[b] = sw ? c[a] : c[b];                                                             \
+        s[a] = ts;                                                                           \
+        c[a] = tc;                                                                           \
+    }
+        CSWAP(0, 1) CSWAP(2, 3) CSWAP(0, 2) CSWAP(1, 3) CSWAP(1, 2)
+#undef CSWAP
+        /* upper bound on the true value of every density outside the four: the 5th key with
+         * its 7 borrowed bits pushed towards +inf */
+        uint32_t kb = __float_as_uint(L[h][4]);
+        float ub = __uint_as_float((kb & 0x80000000u) ? (kb & ~127u) : (kb | 127u));
+        int irest = dens2int(ub);
+        bool proven = s[0] > s[1] && s[1] > s[2] && s[2] > s[3] && s[3] > irest;
+        if (tt[h] < P.n_frames) {
+            size_t idx = (size_t)tt[h] * P.n_cbf + cbf;
+            P.topn_cw[idx] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16)
+                | ((uint32_t)c[3] << 24);
+            P.topn_sc[idx] = make_int4(s[0], s[1], s[2], s[3]);
+            if (!proven)
+                atomicOr(&P.flags[idx >> 5], 1u << (idx & 31));
         }
     }
 }
@@ -767,7 +993,12 @@ struct ssw_model_s {
     uint32_t *d_topn_cw;
     int4 *d_topn_sc;
     int *d_utt_off;
+    uint32_t *d_flags;          /* bit per (frame, cbf): needs the exact pass */
+    unsigned long long *d_nfixed;
     size_t ws_frames, ws_utts;
+    std::vector<int32_t> *utt_cache; /* last uploaded utterance offsets */
+    int force_exact;            /* SSW_PTM_EXACT=1: always run the sequential chain kernel */
+    int stats_pending;
     int last_n_frames;
     int64_t stats[2];
     /* optional per-kernel event timing */
@@ -872,6 +1103,10 @@ ssw_model_load(const char *mdef, const char *means, const char *variances, const
         ssw_model_free(m);
         return NULL;
     }
+    {
+        const char *e = getenv("SSW_PTM_EXACT");
+        m->force_exact = (e != NULL && e[0] == '1');
+    }
     return m;
 }
 
@@ -888,6 +1123,9 @@ ssw_model_free(ssw_model_t *m)
     (void)hipFree(m->d_topn_cw);
     (void)hipFree(m->d_topn_sc);
     (void)hipFree(m->d_utt_off);
+    (void)hipFree(m->d_flags);
+    (void)hipFree(m->d_nfixed);
+    delete m->utt_cache;
     (void)hipFree(m->d_feats);
     (void)hipFree(m->d_out);
     if (m->timing)
@@ -959,13 +1197,21 @@ ensure_score_ws(ssw_model_s *m, int n_frames, int n_utts)
     if ((size_t)n_frames > m->ws_frames) {
         (void)hipFree(m->d_topn_cw);
         (void)hipFree(m->d_topn_sc);
+        (void)hipFree(m->d_flags);
         m->d_topn_cw = NULL;
         m->d_topn_sc = NULL;
+        m->d_flags = NULL;
         m->ws_frames = 0;
         if (dev_alloc(&m->d_topn_cw, (size_t)n_frames * m->n_cbf) < 0
-            || dev_alloc(&m->d_topn_sc, (size_t)n_frames * m->n_cbf) < 0)
+            || dev_alloc(&m->d_topn_sc, (size_t)n_frames * m->n_cbf) < 0
+            || dev_alloc(&m->d_flags, ((size_t)n_frames * m->n_cbf + 31) / 32 + 64) < 0)
             return -1;
         m->ws_frames = (size_t)n_frames;
+    }
+    if (m->d_nfixed == NULL) {
+        if (dev_alloc(&m->d_nfixed, 1) < 0)
+            return -1;
+        HIP_OK(hipMemset(m->d_nfixed, 0, sizeof(unsigned long long)));
     }
     if ((size_t)n_utts + 1 > m->ws_utts) {
         (void)hipFree(m->d_utt_off);
@@ -1073,17 +1319,67 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
     HIP_OK(hipSetDevice(m->device));
     if (ensure_score_ws(m, n_frames, n_utts) < 0)
         return -1;
-    HIP_OK(hipMemcpyAsync(m->d_utt_off, utt_off, sizeof(int32_t) * ((size_t)n_utts + 1),
-                          hipMemcpyHostToDevice, st));
+    /* the offsets rarely change between calls of one job: upload only when they do */
+    if (m->utt_cache == NULL)
+        m->utt_cache = new std::vector<int32_t>();
+    if (m->utt_cache->size() != (size_t)n_utts + 1
+        || memcmp(m->utt_cache->data(), utt_off, sizeof(int32_t) * ((size_t)n_utts + 1)) != 0) {
+        m->utt_cache->assign(utt_off, utt_off + n_utts + 1);
+        HIP_OK(hipStreamSynchronize(st)); /* earlier launches may still read the old offsets */
+        HIP_OK(hipMemcpy(m->d_utt_off, utt_off, sizeof(int32_t) * ((size_t)n_utts + 1),
+                         hipMemcpyHostToDevice));
+    }
+    const ssw_host_model_t *h = m->h;
     ChainParams P;
     fill_chain_params(m, P, d_feats);
     P.n_utts = n_utts;
-    int n_chain = n_utts * m->n_cbf;
+    P.n_frames = n_frames;
+    P.flags = m->d_flags;
+    const int64_t pairs = (int64_t)n_frames * m->n_cbf;
     if (m->timing)
         HIP_OK(hipEventRecord(m->ev[0], st));
-    hipLaunchKernelGGL((ptm_topn_chain_kernel<13, 2, 4, 0>), dim3((n_chain + 3) / 4), dim3(256),
-                       0, st, P);
-    HIP_OK(hipGetLastError());
+    if (h->cfg.ds != 1 || m->force_exact) {
+        /* frame down-sampling makes every frame depend on its predecessor: exact chains */
+        int n_chain = n_utts * m->n_cbf;
+        hipLaunchKernelGGL((ptm_topn_chain_kernel<13, 2, 4>), dim3((n_chain + 3) / 4),
+                           dim3(256), 0, st, P);
+        HIP_OK(hipGetLastError());
+        m->stats[0] = pairs;
+        m->stats_pending = 0;
+    } else {
+        const int n_words = (int)((pairs + 31) / 32);
+        HIP_OK(hipMemsetAsync(m->d_flags, 0, sizeof(uint32_t) * (size_t)n_words, st));
+        HIP_OK(hipMemsetAsync(m->d_nfixed, 0, sizeof(unsigned long long), st));
+        FramesParams F;
+        memset(&F, 0, sizeof(F));
+        F.topn_cw = m->d_topn_cw;
+        F.topn_sc = m->d_topn_sc;
+        F.flags = m->d_flags;
+        F.n_frames = n_frames;
+        F.n_cbf = m->n_cbf;
+        F.n_feat = h->n_feat;
+        F.featdim = h->veclen_total;
+        for (int f = 0; f < h->n_feat; ++f)
+            F.featoff[f] = h->featoff[f];
+        /* two frames per lane once that still fills the chip with >= 4 waves per SIMD */
+        const bool two = (int64_t)((n_frames + 127) / 128) * m->n_cbf >= 4096;
+        const int fpl = two ? 2 : 1;
+        const int tiles = (n_frames + 64 * fpl - 1) / (64 * fpl);
+        dim3 grid((tiles + 3) / 4, m->n_cbf);
+        if (two)
+            hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 2>), grid, dim3(256), 0, st, m->d_rec,
+                               d_feats, F);
+        else
+            hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 1>), grid, dim3(256), 0, st, m->d_rec,
+                               d_feats, F);
+        HIP_OK(hipGetLastError());
+        int fix_blocks = (n_words + 63) / 64;
+        fix_blocks = fix_blocks > 2048 ? 2048 : fix_blocks;
+        hipLaunchKernelGGL((ptm_topn_fixup_kernel<13, 2, 4>), dim3(fix_blocks), dim3(64), 0, st,
+                           P, n_words, m->d_nfixed);
+        HIP_OK(hipGetLastError());
+        m->stats_pending = 1;
+    }
     if (m->timing)
         HIP_OK(hipEventRecord(m->ev[1], st));
     if (launch_senone(m, n_frames, m->d_topn_cw, m->d_topn_sc, d_out, st) < 0)
@@ -1091,8 +1387,7 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
     if (m->timing)
         HIP_OK(hipEventRecord(m->ev[2], st));
     m->last_n_frames = n_frames;
-    m->stats[0] = (int64_t)n_frames * m->n_cbf;
-    m->stats[1] = (int64_t)n_frames * m->n_cbf;
+    m->stats[1] = pairs;
     return 0;
 }
 
@@ -1172,6 +1467,14 @@ ssw_get_kernel_timing(ssw_model_t *m, float *ms, int n)
 extern "C" int
 ssw_score_batch_stats(ssw_model_t *m, int64_t stats[2])
 {
+    if (m->stats_pending) {
+        unsigned long long n = 0;
+        HIP_OK(hipSetDevice(m->device));
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemcpy(&n, m->d_nfixed, sizeof(n), hipMemcpyDeviceToHost));
+        m->stats[0] = (int64_t)n;
+        m->stats_pending = 0;
+    }
     stats[0] = m->stats[0];
     stats[1] = m->stats[1];
     return 0;
@@ -1457,7 +1760,7 @@ mgau_frame_eval(ssw_mgau_t *mg, int16_t *senscr, uint8_t *senone_active,
         P.topn_cw = g->d_hist_cw[slot];
         P.topn_sc = g->d_hist_sc[slot];
         P.frame_base = frame;
-        hipLaunchKernelGGL((ptm_topn_chain_kernel<13, 2, 4, 0>), dim3((m->n_cbf + 3) / 4),
+        hipLaunchKernelGGL((ptm_topn_chain_kernel<13, 2, 4>), dim3((m->n_cbf + 3) / 4),
                            dim3(256), 0, 0, P);
         HIP_OK(hipGetLastError());
     }

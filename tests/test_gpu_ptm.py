@@ -37,3 +37,30 @@ def test_ptm_small_batch_bit_exact(gpu_en, orc_en, means_en):
     assert np.array_equal(gcw.astype(np.int32), rcw)
     assert got.dtype == np.int16 and got.shape == ref.shape
     assert np.array_equal(got, ref)
+
+
+def test_ptm_config2_layouts_bit_exact(gpu_en, orc_en, means_en):
+    """BASELINE config 2: 4096 frames as 16 x 256 and as 1 x 4096, full int16 parity, and the
+    top-N state (codeword order) of every frame."""
+    feats = np.concatenate([synth_features(means_en, 256, 12345 + i) for i in range(16)])
+    for utt_off in (np.arange(17, dtype=np.int32) * 256, np.array([0, 4096], np.int32)):
+        got = gpu_en.score_batch(feats, utt_off)
+        flagged, pairs = gpu_en.last_stats()
+        gcw, _ = gpu_en.last_topn(len(feats))
+        ref, rcw, _ = _oracle_batch(orc_en, feats, utt_off)
+        assert pairs == 4096 * 126
+        assert 0 < flagged < pairs // 20, "exact pass should be rare but not empty here"
+        assert np.array_equal(gcw.astype(np.int32), rcw)
+        assert np.array_equal(got, ref)
+
+
+def test_ptm_correlated_frames_bit_exact(gpu_en, orc_en, means_en):
+    """Slowly drifting features (speech-like): carried top-N codewords stay good, the regime in
+    which the reference's history matters most."""
+    base = synth_features(means_en, 8, 777)
+    t = np.linspace(0, 1, 300, dtype=np.float32)[:, None]
+    feats = (base[0] * (1 - t) + base[1] * t).astype(np.float32)
+    feats = np.concatenate([feats, np.repeat(base[2:3], 40, axis=0)])  # identical frames too
+    got = gpu_en.score_batch(feats)
+    ref = orc_en.ptm_score_utt(feats)
+    assert np.array_equal(got, ref)
