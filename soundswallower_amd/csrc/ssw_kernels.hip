@@ -330,9 +330,11 @@ ptm_topn_fixup_kernel(ChainParams P, int n_words, unsigned long long *n_fixed)
     float mean[NDL][VECLEN], var[NDL][VECLEN], det[NDL];
     int loaded_cbf = -1;
     unsigned long long fixed = 0;
-    for (int chunk = blockIdx.x; chunk * 64 < n_words; chunk += gridDim.x) {
-        int widx = chunk * 64 + lane;
-        uint32_t word = widx < n_words ? P.flags[widx] : 0u;
+    constexpr int WPW = 8; /* flag words per wave and sweep step: small, so that flagged pairs
+                            * spread over many waves and the pass is one item deep */
+    for (int chunk = blockIdx.x; chunk * WPW < n_words; chunk += gridDim.x) {
+        int widx = chunk * WPW + lane;
+        uint32_t word = (lane < WPW && widx < n_words) ? P.flags[widx] : 0u;
         unsigned long long wmask = __ballot(word != 0);
         while (wmask) {
             int l = __builtin_ctzll(wmask);
@@ -341,7 +343,7 @@ ptm_topn_fixup_kernel(ChainParams P, int n_words, unsigned long long *n_fixed)
             while (w) {
                 int b = __builtin_ctz(w);
                 w &= w - 1;
-                long long bit = ((long long)(chunk * 64 + l) << 5) + b;
+                long long bit = ((long long)(chunk * WPW + l) << 5) + b;
                 int t = (int)(bit / P.n_cbf);
                 int cbf = (int)(bit - (long long)t * P.n_cbf);
                 /* utterance of frame t: last u with utt_off[u] <= t */
@@ -418,6 +420,7 @@ ptm_topn_fixup_kernel(ChainParams P, int n_words, unsigned long long *n_fixed)
  *     sequential state machine.
  */
 typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 struct FramesParams {
     uint32_t *topn_cw;
@@ -468,44 +471,78 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
         for (int k = 0; k < 5; ++k)
             L[h][k] = NEG_INF;
 
-    for (int cw = 0; cw < 128; ++cw) {
-        const float *r = rec_cbf + cw * SSW_REC_FLOATS; /* wave-uniform: scalar loads */
-        float d[FPL];
-        if (FPL == 2) {
-            float2v dd = { r[SSW_REC_DET], r[SSW_REC_DET] };
-#pragma unroll
-            for (int j = 0; j < VECLEN; ++j) {
-                float2v xx = { x[0][j], x[FPL - 1][j] };
-                float2v mm = { r[j], r[j] };
-                float2v vv = { r[SSW_REC_VAR + j], r[SSW_REC_VAR + j] };
-                float2v diff = xx - mm;
-                float2v sq = diff * diff;
-                float2v c = sq * vv;
-                dd = dd - c;
-            }
-            d[0] = dd.x;
-            d[FPL - 1] = dd.y;
-        } else {
-            float dd = r[SSW_REC_DET];
-#pragma unroll
-            for (int j = 0; j < VECLEN; ++j) {
-                float diff = x[0][j] - r[j];
-                float sq = diff * diff;
-                float c = sq * r[SSW_REC_VAR + j];
-                dd = dd - c;
-            }
-            d[0] = dd;
-        }
-#pragma unroll
-        for (int h = 0; h < FPL; ++h) {
-            float key = __uint_as_float((__float_as_uint(d[h]) & ~127u) | (uint32_t)cw);
-            L[h][4] = med3f(L[h][3], L[h][4], key);
-            L[h][3] = med3f(L[h][2], L[h][3], key);
-            L[h][2] = med3f(L[h][1], L[h][2], key);
-            L[h][1] = med3f(L[h][0], L[h][1], key);
-            L[h][0] = med3f(L[h][0], POS_INF, key);
-        }
+    /* The 128 records stream through SGPRs, double-buffered by hand: the loads of record
+     * cw+1 are issued before the arithmetic on record cw and waited for after it.  They are
+     * inline asm because SMEM returns out of order (only lgkmcnt(0) is meaningful) and the
+     * compiler would otherwise issue and wait in one place; the operand ties keep issue, use
+     * and wait in this order, and keep every register of a tuple reserved while its load is
+     * in flight. */
+    uint32_t keymask;
+    asm volatile("v_mov_b32 %0, 0xffffff80" : "=v"(keymask));
+    v16f a_lo, a_hi, b_lo, b_hi;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40"
+                 : "=&s"(a_lo), "=&s"(a_hi)
+                 : "s"(rec_cbf));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a_lo), "+s"(a_hi));
+
+#define SSW_REC_ISSUE(lo, hi, ptr, tie)                                                      \
+    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40"              \
+                 : "=&s"(lo), "=&s"(hi), "+s"(tie)                                           \
+                 : "s"(ptr))
+#define SSW_REC_WAIT(lo, hi, vtie) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lo), "+s"(hi), "+v"(vtie))
+#define SSW_REC_SCAN(lo, hi, cwv)                                                            \
+    {                                                                                        \
+        float d[FPL];                                                                        \
+        if (FPL == 2) {                                                                      \
+            float2v dd = { lo[SSW_REC_DET], lo[SSW_REC_DET] };                               \
+            _Pragma("unroll") for (int j = 0; j < VECLEN; ++j)                               \
+            {                                                                                \
+                float2v xx = { x[0][j], x[FPL - 1][j] };                                     \
+                float2v mm = { lo[j], lo[j] };                                               \
+                float2v vv = { hi[j], hi[j] };                                               \
+                float2v diff = xx - mm;                                                      \
+                float2v sq = diff * diff;                                                    \
+                float2v c = sq * vv;                                                         \
+                dd = dd - c;                                                                 \
+            }                                                                                \
+            d[0] = dd.x;                                                                     \
+            d[FPL - 1] = dd.y;                                                               \
+        } else {                                                                             \
+            float dd = lo[SSW_REC_DET];                                                      \
+            _Pragma("unroll") for (int j = 0; j < VECLEN; ++j)                               \
+            {                                                                                \
+                float diff = x[0][j] - lo[j];                                                \
+                float sq = diff * diff;                                                      \
+                float c = sq * hi[j];                                                        \
+                dd = dd - c;                                                                 \
+            }                                                                                \
+            d[0] = dd;                                                                       \
+        }                                                                                    \
+        _Pragma("unroll") for (int h = 0; h < FPL; ++h)                                      \
+        {                                                                                    \
+            float key = __uint_as_float((__float_as_uint(d[h]) & keymask) | (uint32_t)(cwv)); \
+            L[h][4] = med3f(L[h][3], L[h][4], key);                                          \
+            L[h][3] = med3f(L[h][2], L[h][3], key);                                          \
+            L[h][2] = med3f(L[h][1], L[h][2], key);                                          \
+            L[h][1] = med3f(L[h][0], L[h][1], key);                                          \
+            asm("v_max_f32 %0, %1, %2" : "=v"(L[h][0]) : "v"(L[h][0]), "v"(key));           \
+        }                                                                                    \
     }
+
+    static_assert(SSW_REC_VAR == 16 && SSW_REC_FLOATS == 32, "record = two 16-dword halves");
+    for (int cw = 0; cw < 128; cw += 2) {
+        const float *rb = rec_cbf + (cw + 1) * SSW_REC_FLOATS;
+        SSW_REC_ISSUE(b_lo, b_hi, rb, a_lo);
+        SSW_REC_SCAN(a_lo, a_hi, cw);
+        SSW_REC_WAIT(b_lo, b_hi, L[FPL - 1][0]);
+        const float *ra = rec_cbf + (cw + 2 < 128 ? cw + 2 : 127) * SSW_REC_FLOATS;
+        SSW_REC_ISSUE(a_lo, a_hi, ra, b_lo);
+        SSW_REC_SCAN(b_lo, b_hi, cw + 1);
+        SSW_REC_WAIT(a_lo, a_hi, L[FPL - 1][0]);
+    }
+#undef SSW_REC_ISSUE
+#undef SSW_REC_WAIT
+#undef SSW_REC_SCAN
 
 #pragma unroll
     for (int h = 0; h < FPL; ++h) {
@@ -567,33 +604,50 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
 /* ---------------------------------------------------------------------------------- */
 
 struct SenoneParams {
-    const uint32_t *topn_cw; /* [n_frames][n_cbf] */
-    const int4 *topn_sc;     /* [n_frames][n_cbf] raw */
-    const uint8_t *mixw;     /* [n_feat][n_density][sen_stride] */
-    const uint8_t *sen2cb;   /* [n_sen] */
+    const uint32_t *topn_cw; /* [n_frames][n_cbf] 4 codewords packed */
+    const int4 *topn_sc;     /* [n_frames][n_cbf] raw scores */
+    const uint8_t *mixw;     /* [n_feat][n_density][slot_stride], slot order */
+    const uint8_t *quad_cb;  /* [n_quads] codebook of slots 4q..4q+3 */
+    const short4 *slot_sen;  /* [n_quads] senone ids of the 4 slots, -1 = padding */
     const uint8_t *logadd8;  /* [256] */
+    uint32_t *flags;         /* optional: flag words of this frame are cleared for the next call */
+    unsigned long long *nfixed; /* optional: [0] running count of the fix-up pass, [1] last batch */
     int16_t *out;            /* [n_frames][n_sen] */
-    int n_frames, n_cb, n_feat, n_density, n_sen, sen_stride;
+    int n_frames, n_cb, n_feat, n_density, n_sen, slot_stride, n_quads;
 };
 
-constexpr int SEN_THREADS = 1024;
-constexpr int SEN_MAX_PER_THREAD = 8; /* n_sen <= 8192 */
+constexpr int SEN_MAX_THREADS = 1024;
 
-template <int TOPN>
-__global__ void __launch_bounds__(SEN_THREADS)
+/* fast_logmath_add (tied_mgau_common.h:100-117): min(x, y) - table[|x - y|] */
+__device__ __forceinline__ int
+fast_logadd(int x, int y, const uint8_t *tab)
+{
+    int d = (int)__builtin_amdgcn_sad_u16((unsigned)x, (unsigned)y, 0u); /* |x - y|, both < 2^16 */
+    int r = x < y ? x : y;
+    return r - (int)tab[d];
+}
+
+/* One workgroup per frame.  Senones are visited in "slot" order: grouped by codebook, each
+ * group padded to a multiple of 4, so one lane owns 4 consecutive slots that share their top-N
+ * block and fetches the 4 mixture weights of a (stream, codeword) row with one dword load.
+ * R = quads per thread. */
+template <int TOPN, int R>
+__global__ void __launch_bounds__(SEN_MAX_THREADS)
 ptm_senone_kernel(SenoneParams P)
 {
+    static_assert(TOPN == 4, "top-N block is packed 4 x 8 bit");
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_cbf = P.n_cb * P.n_feat;
-    /* LDS carve: logadd[256] | norm[n_feat] int | ns[n_cbf*TOPN] u8 | cw[n_cbf*TOPN] u8 | red */
+    /* LDS carve: logadd[256] | norm[8] | ns4[n_cbf] | cw4[n_cbf] | red[16] */
     uint8_t *s_tab = smem;
     int *s_norm = reinterpret_cast<int *>(smem + 256);
-    uint8_t *s_ns = smem + 256 + 4 * SSW_MAX_FEAT;
-    uint8_t *s_cw = s_ns + ((n_cbf * TOPN + 15) & ~15);
-    int *s_red = reinterpret_cast<int *>(s_cw + ((n_cbf * TOPN + 15) & ~15));
+    uint32_t *s_ns4 = reinterpret_cast<uint32_t *>(smem + 256 + 4 * SSW_MAX_FEAT);
+    uint32_t *s_cw4 = s_ns4 + n_cbf;
+    int *s_red = reinterpret_cast<int *>(s_cw4 + n_cbf);
 
     const int t = blockIdx.x;
     const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
     const uint32_t *cwrow = P.topn_cw + (size_t)t * n_cbf;
     const int4 *scrow = P.topn_sc + (size_t)t * n_cbf;
 
@@ -608,49 +662,73 @@ ptm_senone_kernel(SenoneParams P)
         }
         s_norm[tid] = norm;
     }
+    if (P.flags != nullptr) { /* this frame's flag bits have been consumed by the fix-up pass */
+        long long b0 = (long long)t * n_cbf, b1 = b0 + n_cbf - 1;
+        int w0 = (int)(b0 >> 5), w1 = (int)(b1 >> 5);
+        if (tid <= w1 - w0)
+            P.flags[w0 + tid] = 0u;
+        if (t == 0 && tid == 0) {
+            P.nfixed[1] = P.nfixed[0];
+            P.nfixed[0] = 0ull;
+        }
+    }
     __syncthreads();
     /* s = min(96, -((s >> 10) - norm)), src/ptm_mgau.c:284-290 */
-    for (int i = tid; i < n_cbf; i += SEN_THREADS) {
+    for (int i = tid; i < n_cbf; i += nthr) {
         int4 sc = scrow[i];
-        uint32_t pk = cwrow[i];
         int norm = s_norm[i % P.n_feat];
         int v[4] = { sc.x, sc.y, sc.z, sc.w };
+        uint32_t pk = 0;
 #pragma unroll
         for (int k = 0; k < TOPN; ++k) {
-            int s = -((v[k] >> SSW_SENSCR_SHIFT) - norm);
-            s = s > SSW_MAX_NEG_ASCR ? SSW_MAX_NEG_ASCR : s;
-            s_ns[i * TOPN + k] = (uint8_t)s;
-            s_cw[i * TOPN + k] = (uint8_t)(pk >> (8 * k));
+            int q = -((v[k] >> SSW_SENSCR_SHIFT) - norm);
+            q = q > SSW_MAX_NEG_ASCR ? SSW_MAX_NEG_ASCR : q;
+            pk |= (uint32_t)(q & 0xff) << (8 * k);
         }
+        s_ns4[i] = pk;
+        s_cw4[i] = cwrow[i];
     }
     __syncthreads();
 
     /* senone combine, src/ptm_mgau.c:342-395 */
-    int asc[SEN_MAX_PER_THREAD];
+    int asc[R][4];
     int best = INT_MAX;
 #pragma unroll
-    for (int r = 0; r < SEN_MAX_PER_THREAD; ++r) {
-        int sen = r * SEN_THREADS + tid;
-        asc[r] = 0;
-        if (sen < P.n_sen) {
-            int cb = P.sen2cb[sen];
-            int a = 0;
-            for (int f = 0; f < P.n_feat; ++f) {
-                int base = (cb * P.n_feat + f) * TOPN;
-                const uint8_t *mw = P.mixw + (size_t)f * P.n_density * P.sen_stride + sen;
-                int fden = (int)mw[(size_t)s_cw[base] * P.sen_stride] + (int)s_ns[base];
+    for (int r = 0; r < R; ++r) {
+        const int q = r * nthr + tid;
 #pragma unroll
-                for (int k = 1; k < TOPN; ++k) {
-                    int y = (int)mw[(size_t)s_cw[base + k] * P.sen_stride] + (int)s_ns[base + k];
-                    /* fast_logmath_add, tied_mgau_common.h:100-117 */
-                    int d = fden > y ? fden - y : y - fden;
-                    int r2 = fden > y ? y : fden;
-                    fden = r2 - (int)s_tab[d];
+        for (int j = 0; j < 4; ++j)
+            asc[r][j] = 0;
+        if (q < P.n_quads) {
+            const int cb = P.quad_cb[q];
+            const uint8_t *mq = P.mixw + (size_t)q * 4;
+            for (int f = 0; f < P.n_feat; ++f) {
+                const uint32_t cw4 = s_cw4[cb * P.n_feat + f];
+                const uint32_t ns4 = s_ns4[cb * P.n_feat + f];
+                uint32_t mw[TOPN];
+#pragma unroll
+                for (int k = 0; k < TOPN; ++k) {
+                    const uint32_t cw = (cw4 >> (8 * k)) & 0xffu;
+                    mw[k] = *reinterpret_cast<const uint32_t *>(
+                        mq + ((size_t)f * P.n_density + cw) * P.slot_stride);
                 }
-                a += fden;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int fden = (int)((mw[0] >> (8 * j)) & 0xffu) + (int)(ns4 & 0xffu);
+#pragma unroll
+                    for (int k = 1; k < TOPN; ++k) {
+                        int y = (int)((mw[k] >> (8 * j)) & 0xffu) + (int)((ns4 >> (8 * k)) & 0xffu);
+                        fden = fast_logadd(fden, y, s_tab);
+                    }
+                    asc[r][j] += fden;
+                }
             }
-            asc[r] = a;
-            best = a < best ? a : best;
+            const short4 sen = P.slot_sen[q];
+            const int sj[4] = { sen.x, sen.y, sen.z, sen.w };
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (sj[j] >= 0)
+                    best = asc[r][j] < best ? asc[r][j] : best;
         }
     }
     /* block minimum */
@@ -662,8 +740,8 @@ ptm_senone_kernel(SenoneParams P)
     if ((tid & 63) == 0)
         s_red[tid >> 6] = best;
     __syncthreads();
-    if (tid < SEN_THREADS / 64) {
-        int b = s_red[tid];
+    if (tid < 64) {
+        int b = tid < (nthr >> 6) ? s_red[tid] : INT_MAX;
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) {
             int o = __shfl_xor(b, off, WAVE);
@@ -676,10 +754,16 @@ ptm_senone_kernel(SenoneParams P)
     best = s_red[0];
     int16_t *orow = P.out + (size_t)t * P.n_sen;
 #pragma unroll
-    for (int r = 0; r < SEN_MAX_PER_THREAD; ++r) {
-        int sen = r * SEN_THREADS + tid;
-        if (sen < P.n_sen) /* int16 arithmetic as in src/ptm_mgau.c:394-400 */
-            orow[sen] = (int16_t)((int16_t)asc[r] - (int16_t)best);
+    for (int r = 0; r < R; ++r) {
+        const int q = r * nthr + tid;
+        if (q < P.n_quads) {
+            const short4 sen = P.slot_sen[q];
+            const int sj[4] = { sen.x, sen.y, sen.z, sen.w };
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (sj[j] >= 0) /* int16 arithmetic as in src/ptm_mgau.c:394-400 */
+                    orow[sj[j]] = (int16_t)((int16_t)asc[r][j] - (int16_t)best);
+        }
     }
 }
 
@@ -988,7 +1072,9 @@ struct ssw_model_s {
     int device;
     int n_cbf, sen_stride;
     float *d_rec;
-    uint8_t *d_mixw, *d_sen2cb, *d_logadd8, *d_tp;
+    uint8_t *d_mixw, *d_sen2cb, *d_logadd8, *d_tp, *d_quad_cb;
+    short4 *d_slot_sen;
+    int n_quads, slot_stride;
     /* scoring workspace */
     uint32_t *d_topn_cw;
     int4 *d_topn_sc;
@@ -1051,13 +1137,35 @@ upload_model(ssw_model_s *m)
         HIP_OK(hipMemcpy(m->d_sen2cb, s2c.data(), s2c.size(), hipMemcpyHostToDevice));
     }
     if (h->ptm_mixw) {
-        m->sen_stride = (h->n_sen + 127) & ~127;
-        std::vector<uint8_t> mw((size_t)h->n_feat * h->n_density * m->sen_stride, 0);
+        /* slot order: senones grouped by codebook (ascending id inside a group), every group
+         * padded to a multiple of 4 slots */
+        std::vector<int16_t> slot_sen;
+        std::vector<uint8_t> quad_cb;
+        for (int c = 0; c < h->n_cb; ++c) {
+            size_t start = slot_sen.size();
+            for (int i = 0; i < h->n_sen; ++i)
+                if (h->sen2cb[i] == c)
+                    slot_sen.push_back((int16_t)i);
+            while ((slot_sen.size() - start) % 4)
+                slot_sen.push_back(-1);
+            for (size_t q = start / 4; q < slot_sen.size() / 4; ++q)
+                quad_cb.push_back((uint8_t)c);
+        }
+        m->n_quads = (int)quad_cb.size();
+        m->slot_stride = ((int)slot_sen.size() + 127) & ~127;
+        m->sen_stride = m->slot_stride;
+        std::vector<uint8_t> mw((size_t)h->n_feat * h->n_density * m->slot_stride, 0);
         for (int r = 0; r < h->n_feat * h->n_density; ++r)
-            memcpy(mw.data() + (size_t)r * m->sen_stride, h->ptm_mixw + (size_t)r * h->n_sen,
-                   (size_t)h->n_sen);
+            for (size_t sl = 0; sl < slot_sen.size(); ++sl)
+                if (slot_sen[sl] >= 0)
+                    mw[(size_t)r * m->slot_stride + sl] = h->ptm_mixw[(size_t)r * h->n_sen + slot_sen[sl]];
         HIP_OK(hipMalloc((void **)&m->d_mixw, mw.size()));
         HIP_OK(hipMemcpy(m->d_mixw, mw.data(), mw.size(), hipMemcpyHostToDevice));
+        HIP_OK(hipMalloc((void **)&m->d_quad_cb, quad_cb.size()));
+        HIP_OK(hipMemcpy(m->d_quad_cb, quad_cb.data(), quad_cb.size(), hipMemcpyHostToDevice));
+        HIP_OK(hipMalloc((void **)&m->d_slot_sen, slot_sen.size() * sizeof(int16_t)));
+        HIP_OK(hipMemcpy(m->d_slot_sen, slot_sen.data(), slot_sen.size() * sizeof(int16_t),
+                         hipMemcpyHostToDevice));
     }
     if (h->tp) {
         size_t n = (size_t)h->tp_n_tmat * h->tp_n_state * (h->tp_n_state + 1);
@@ -1118,6 +1226,8 @@ ssw_model_free(ssw_model_t *m)
     (void)hipFree(m->d_rec);
     (void)hipFree(m->d_mixw);
     (void)hipFree(m->d_sen2cb);
+    (void)hipFree(m->d_quad_cb);
+    (void)hipFree(m->d_slot_sen);
     (void)hipFree(m->d_logadd8);
     (void)hipFree(m->d_tp);
     (void)hipFree(m->d_topn_cw);
@@ -1206,12 +1316,14 @@ ensure_score_ws(ssw_model_s *m, int n_frames, int n_utts)
             || dev_alloc(&m->d_topn_sc, (size_t)n_frames * m->n_cbf) < 0
             || dev_alloc(&m->d_flags, ((size_t)n_frames * m->n_cbf + 31) / 32 + 64) < 0)
             return -1;
+        HIP_OK(hipMemset(m->d_flags, 0,
+                         sizeof(uint32_t) * (((size_t)n_frames * m->n_cbf + 31) / 32 + 64)));
         m->ws_frames = (size_t)n_frames;
     }
     if (m->d_nfixed == NULL) {
-        if (dev_alloc(&m->d_nfixed, 1) < 0)
+        if (dev_alloc(&m->d_nfixed, 2) < 0)
             return -1;
-        HIP_OK(hipMemset(m->d_nfixed, 0, sizeof(unsigned long long)));
+        HIP_OK(hipMemset(m->d_nfixed, 0, 2 * sizeof(unsigned long long)));
     }
     if ((size_t)n_utts + 1 > m->ws_utts) {
         (void)hipFree(m->d_utt_off);
@@ -1243,10 +1355,6 @@ check_ptm_shape(const ssw_model_s *m)
             ssw_set_error("PTM kernels are built for 13-dimensional streams");
             return -1;
         }
-    if (h->n_sen > SEN_THREADS * SEN_MAX_PER_THREAD) {
-        ssw_set_error("too many senones (%d)", h->n_sen);
-        return -1;
-    }
     return 0;
 }
 
@@ -1270,25 +1378,40 @@ fill_chain_params(const ssw_model_s *m, ChainParams &P, const float *d_feats)
 
 static int
 launch_senone(ssw_model_s *m, int n_frames, const uint32_t *cw, const int4 *sc, int16_t *d_out,
-              hipStream_t st)
+              uint32_t *flags, hipStream_t st)
 {
     const ssw_host_model_t *h = m->h;
     SenoneParams S;
     S.topn_cw = cw;
     S.topn_sc = sc;
     S.mixw = m->d_mixw;
-    S.sen2cb = m->d_sen2cb;
+    S.quad_cb = m->d_quad_cb;
+    S.slot_sen = m->d_slot_sen;
     S.logadd8 = m->d_logadd8;
+    S.flags = flags;
+    S.nfixed = m->d_nfixed;
     S.out = d_out;
     S.n_frames = n_frames;
     S.n_cb = h->n_cb;
     S.n_feat = h->n_feat;
     S.n_density = h->n_density;
     S.n_sen = h->n_sen;
-    S.sen_stride = m->sen_stride;
-    size_t part = ((size_t)m->n_cbf * 4 + 15) & ~(size_t)15;
-    size_t lds = 256 + 4 * SSW_MAX_FEAT + 2 * part + 64 * sizeof(int);
-    hipLaunchKernelGGL(ptm_senone_kernel<4>, dim3(n_frames), dim3(SEN_THREADS), lds, st, S);
+    S.slot_stride = m->slot_stride;
+    S.n_quads = m->n_quads;
+    size_t lds = 256 + 4 * SSW_MAX_FEAT + 8 * (size_t)m->n_cbf + 16 * sizeof(int);
+    const int R = (m->n_quads + SEN_MAX_THREADS - 1) / SEN_MAX_THREADS;
+    int threads = ((m->n_quads + R - 1) / R + 63) & ~63;
+    if (threads < 256)
+        threads = 256; /* the prologue copies the 256-entry table with the first 256 threads */
+    switch (R) {
+    case 1: hipLaunchKernelGGL((ptm_senone_kernel<4, 1>), dim3(n_frames), dim3(threads), lds, st, S); break;
+    case 2: hipLaunchKernelGGL((ptm_senone_kernel<4, 2>), dim3(n_frames), dim3(threads), lds, st, S); break;
+    case 3: hipLaunchKernelGGL((ptm_senone_kernel<4, 3>), dim3(n_frames), dim3(threads), lds, st, S); break;
+    case 4: hipLaunchKernelGGL((ptm_senone_kernel<4, 4>), dim3(n_frames), dim3(threads), lds, st, S); break;
+    default:
+        ssw_set_error("too many senones (%d quads)", m->n_quads);
+        return -1;
+    }
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -1348,8 +1471,8 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
         m->stats_pending = 0;
     } else {
         const int n_words = (int)((pairs + 31) / 32);
-        HIP_OK(hipMemsetAsync(m->d_flags, 0, sizeof(uint32_t) * (size_t)n_words, st));
-        HIP_OK(hipMemsetAsync(m->d_nfixed, 0, sizeof(unsigned long long), st));
+        /* flags are all-zero here: zeroed at allocation, and the senone kernel clears each
+         * frame's words once the fix-up pass has consumed them */
         FramesParams F;
         memset(&F, 0, sizeof(F));
         F.topn_cw = m->d_topn_cw;
@@ -1362,7 +1485,7 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
         for (int f = 0; f < h->n_feat; ++f)
             F.featoff[f] = h->featoff[f];
         /* two frames per lane once that still fills the chip with >= 4 waves per SIMD */
-        const bool two = (int64_t)((n_frames + 127) / 128) * m->n_cbf >= 4096;
+        const bool two = (int64_t)((n_frames + 127) / 128) * m->n_cbf >= 2048;
         const int fpl = two ? 2 : 1;
         const int tiles = (n_frames + 64 * fpl - 1) / (64 * fpl);
         dim3 grid((tiles + 3) / 4, m->n_cbf);
@@ -1373,8 +1496,8 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
             hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 1>), grid, dim3(256), 0, st, m->d_rec,
                                d_feats, F);
         HIP_OK(hipGetLastError());
-        int fix_blocks = (n_words + 63) / 64;
-        fix_blocks = fix_blocks > 2048 ? 2048 : fix_blocks;
+        int fix_blocks = (n_words + 7) / 8;
+        fix_blocks = fix_blocks > 8192 ? 8192 : fix_blocks;
         hipLaunchKernelGGL((ptm_topn_fixup_kernel<13, 2, 4>), dim3(fix_blocks), dim3(64), 0, st,
                            P, n_words, m->d_nfixed);
         HIP_OK(hipGetLastError());
@@ -1382,7 +1505,8 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
     }
     if (m->timing)
         HIP_OK(hipEventRecord(m->ev[1], st));
-    if (launch_senone(m, n_frames, m->d_topn_cw, m->d_topn_sc, d_out, st) < 0)
+    if (launch_senone(m, n_frames, m->d_topn_cw, m->d_topn_sc, d_out,
+                      m->stats_pending ? m->d_flags : NULL, st) < 0)
         return -1;
     if (m->timing)
         HIP_OK(hipEventRecord(m->ev[2], st));
@@ -1471,8 +1595,8 @@ ssw_score_batch_stats(ssw_model_t *m, int64_t stats[2])
         unsigned long long n = 0;
         HIP_OK(hipSetDevice(m->device));
         HIP_OK(hipDeviceSynchronize());
-        HIP_OK(hipMemcpy(&n, m->d_nfixed, sizeof(n), hipMemcpyDeviceToHost));
-        m->stats[0] = (int64_t)n;
+        HIP_OK(hipMemcpy(&n, m->d_nfixed + 1, sizeof(n), hipMemcpyDeviceToHost));
+        m->stats[0] = (int64_t)n; /* moved there by the last batch's senone kernel */
         m->stats_pending = 0;
     }
     stats[0] = m->stats[0];
@@ -1764,7 +1888,7 @@ mgau_frame_eval(ssw_mgau_t *mg, int16_t *senscr, uint8_t *senone_active,
                            dim3(256), 0, 0, P);
         HIP_OK(hipGetLastError());
     }
-    if (launch_senone(m, 1, g->d_hist_cw[slot], g->d_hist_sc[slot], g->d_out1, 0) < 0)
+    if (launch_senone(m, 1, g->d_hist_cw[slot], g->d_hist_sc[slot], g->d_out1, NULL, 0) < 0)
         return -1;
     HIP_OK(hipMemcpy(senscr, g->d_out1, sizeof(int16_t) * h->n_sen, hipMemcpyDeviceToHost));
     return 0;
