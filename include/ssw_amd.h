@@ -34,8 +34,10 @@ typedef struct ssw_config_s {
     int32_t topn;     /* "topn"      4      */
     int32_t ds;       /* "ds"        1      */
     int32_t aw;       /* "aw"        1      */
-    int32_t device;   /* HIP device ordinal; -1 = current device */
+    int32_t device;   /* HIP device ordinal; -1 = current device; SSW_DEVICE_NONE = load the
+                         host tables only (loader checks), every compute call then fails */
 } ssw_config_t;
+#define SSW_DEVICE_NONE (-2)
 
 void ssw_config_defaults(ssw_config_t *cfg);
 const char *ssw_last_error(void);

@@ -653,15 +653,8 @@ ptm_senone_kernel(SenoneParams P)
 
     if (tid < 256)
         s_tab[tid] = P.logadd8[tid];
-    /* per-stream normaliser: max over codebooks of (best >> 10), src/ptm_mgau.c:271-278 */
-    if (tid < P.n_feat) {
-        int norm = SSW_WORST_SCORE;
-        for (int c = 0; c < P.n_cb; ++c) {
-            int top = scrow[c * P.n_feat + tid].x >> SSW_SENSCR_SHIFT;
-            norm = norm < top ? top : norm;
-        }
-        s_norm[tid] = norm;
-    }
+    if (tid < SSW_MAX_FEAT)
+        s_norm[tid] = SSW_WORST_SCORE;
     if (P.flags != nullptr) { /* this frame's flag bits have been consumed by the fix-up pass */
         long long b0 = (long long)t * n_cbf, b1 = b0 + n_cbf - 1;
         int w0 = (int)(b0 >> 5), w1 = (int)(b1 >> 5);
@@ -673,11 +666,20 @@ ptm_senone_kernel(SenoneParams P)
         }
     }
     __syncthreads();
+    /* per-stream normaliser: max over codebooks of (best >> 10), src/ptm_mgau.c:271-278;
+     * one thread per (codebook, stream), combined with LDS atomics */
+    int4 my_sc = make_int4(0, 0, 0, 0);
+    uint32_t my_cw = 0;
+    if (tid < n_cbf) {
+        my_sc = scrow[tid];
+        my_cw = cwrow[tid];
+        atomicMax(&s_norm[tid % P.n_feat], my_sc.x >> SSW_SENSCR_SHIFT);
+    }
+    __syncthreads();
     /* s = min(96, -((s >> 10) - norm)), src/ptm_mgau.c:284-290 */
-    for (int i = tid; i < n_cbf; i += nthr) {
-        int4 sc = scrow[i];
-        int norm = s_norm[i % P.n_feat];
-        int v[4] = { sc.x, sc.y, sc.z, sc.w };
+    if (tid < n_cbf) {
+        int norm = s_norm[tid % P.n_feat];
+        int v[4] = { my_sc.x, my_sc.y, my_sc.z, my_sc.w };
         uint32_t pk = 0;
 #pragma unroll
         for (int k = 0; k < TOPN; ++k) {
@@ -685,8 +687,8 @@ ptm_senone_kernel(SenoneParams P)
             q = q > SSW_MAX_NEG_ASCR ? SSW_MAX_NEG_ASCR : q;
             pk |= (uint32_t)(q & 0xff) << (8 * k);
         }
-        s_ns4[i] = pk;
-        s_cw4[i] = cwrow[i];
+        s_ns4[tid] = pk;
+        s_cw4[tid] = my_cw;
     }
     __syncthreads();
 
@@ -1189,6 +1191,15 @@ ssw_model_load(const char *mdef, const char *means, const char *variances, const
             ssw_host_model_free(h);
             return NULL;
         }
+    if (h->cfg.device == SSW_DEVICE_NONE) {
+        /* host tables only (loader checks without a GPU); every compute entry point refuses */
+        ssw_model_s *hm = new ssw_model_s();
+        memset(hm, 0, sizeof(*hm));
+        hm->h = h;
+        hm->device = SSW_DEVICE_NONE;
+        hm->n_cbf = h->n_cb * h->n_feat;
+        return hm;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         ssw_set_error("no HIP device: the MI355X path has no CPU fallback");
@@ -1223,6 +1234,11 @@ ssw_model_free(ssw_model_t *m)
 {
     if (m == NULL)
         return;
+    if (m->device == SSW_DEVICE_NONE) {
+        ssw_host_model_free(m->h);
+        delete m;
+        return;
+    }
     (void)hipFree(m->d_rec);
     (void)hipFree(m->d_mixw);
     (void)hipFree(m->d_sen2cb);
@@ -1340,6 +1356,11 @@ static int
 check_ptm_shape(const ssw_model_s *m)
 {
     const ssw_host_model_t *h = m->h;
+    if (m->device == SSW_DEVICE_NONE) {
+        ssw_set_error("model was loaded with device = SSW_DEVICE_NONE (tables only): no GPU, "
+                      "no scoring -- there is no CPU fallback");
+        return -1;
+    }
     if (h->ptm_mixw == NULL) {
         ssw_set_error("model has no PTM mixture weights (sendump / mixw)");
         return -1;
@@ -1403,6 +1424,12 @@ launch_senone(ssw_model_s *m, int n_frames, const uint32_t *cw, const int4 *sc, 
     int threads = ((m->n_quads + R - 1) / R + 63) & ~63;
     if (threads < 256)
         threads = 256; /* the prologue copies the 256-entry table with the first 256 threads */
+    if (threads < ((m->n_cbf + 63) & ~63))
+        threads = (m->n_cbf + 63) & ~63; /* ... and owns one (codebook, stream) per thread */
+    if (threads > SEN_MAX_THREADS) {
+        ssw_set_error("too many codebook x stream pairs (%d)", m->n_cbf);
+        return -1;
+    }
     switch (R) {
     case 1: hipLaunchKernelGGL((ptm_senone_kernel<4, 1>), dim3(n_frames), dim3(threads), lds, st, S); break;
     case 2: hipLaunchKernelGGL((ptm_senone_kernel<4, 2>), dim3(n_frames), dim3(threads), lds, st, S); break;
@@ -1522,6 +1549,8 @@ ssw_score_batch_host(ssw_model_t *m, int scorer, const float *feats, int32_t n_f
     const ssw_host_model_t *h = m->h;
     if (n_frames <= 0)
         return 0;
+    if (scorer == SSW_SCORER_PTM && check_ptm_shape(m) < 0)
+        return -1;
     HIP_OK(hipSetDevice(m->device));
     if ((size_t)n_frames > m->st_frames) {
         (void)hipFree(m->d_feats);
@@ -1617,6 +1646,11 @@ ssw_align_batch(ssw_model_t *m, const int16_t *d_senscr, int32_t n_utts,
     hipStream_t st = (hipStream_t)stream;
     if (n_utts <= 0)
         return 0;
+    if (m->device == SSW_DEVICE_NONE) {
+        ssw_set_error("model was loaded with device = SSW_DEVICE_NONE (tables only): no GPU, "
+                      "no alignment -- there is no CPU fallback");
+        return -1;
+    }
     if (h->tp == NULL || h->tp_n_state != 3) {
         ssw_set_error("alignment kernel needs 3-state transition matrices");
         return -1;

@@ -1,0 +1,163 @@
+"""CPU-side checks of the product library: it loads, exports every symbol the header declares,
+its host loaders derive the same tables as the oracle, and compute calls refuse without a GPU."""
+import ctypes as C
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+import soundswallower_amd as ssw
+from soundswallower_amd import _lib
+from tests.conftest import MODEL_ROOT, ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _lib.build()
+    return _lib.lib()
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "ssw_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ssw_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = _declared_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/ssw_amd.h but not exported"
+    assert lib.ssw_abi_version() == 1
+
+
+def test_header_cites_reference_interfaces():
+    text = open(os.path.join(ROOT, "include", "ssw_amd.h")).read()
+    for cite in ("acmod.h:93-111", "src/ptm_mgau.c:408-454", "src/ms_mgau.c:278-368",
+                 "state_align_search.h:89-92", "src/ps_alignment.c:316-352"):
+        assert cite in text
+
+
+def test_no_product_code_touches_the_oracle():
+    """Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may use oracle/."""
+    pkg = os.path.join(ROOT, "soundswallower_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", "Makefile")):
+                body = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in body.replace("the oracle", "").lower() or f == "synth.py", \
+                    f"{f} mentions the oracle"
+
+
+@pytest.mark.parametrize("name", ["en-us", "fr-fr"])
+def test_host_loaders_match_oracle_tables(lib, oracle_mod, name):
+    m = ssw.Model(os.path.join(MODEL_ROOT, name), config={"device": -2})
+    o = oracle_mod.Model(os.path.join(MODEL_ROOT, name))
+    assert (m.n_cb, m.n_feat, m.n_density, m.n_sen, m.n_sseq, m.n_floored, m.sil) == \
+        (o.n_cb, o.n_feat, o.n_density, o.n_sen, o.n_sseq, o.n_floored, o.sil)
+    for tab, ref in (("mean", o.mean), ("var", o.var), ("det", o.det), ("ptm_mixw", o.ptm_mixw),
+                     ("tp", o.tp), ("sseq", o.sseq), ("sen2cb", o.sen2cimap),
+                     ("phone_ssid", o.phone_ssid), ("phone_tmat", o.phone_tmat)):
+        got = m.table(tab)
+        assert got.tobytes() == np.ascontiguousarray(ref).tobytes(), tab
+    assert m.table("logadd8").tolist() == o.logadd_table_8b.tolist()
+
+
+def _write_s3(path, payload, chksum=True):
+    hdr = b"s3\nversion 1.0\n" + (b"chksum0 yes\n" if chksum else b"") + b"endhdr\n"
+    words = np.frombuffer(payload, "<u4")
+    s = 0
+    for w in words.tolist():
+        s = (((s << 20) | (s >> 12)) + w) & 0xFFFFFFFF
+    with open(path, "wb") as fh:
+        fh.write(hdr + struct.pack("<I", 0x11223344) + payload
+                 + (struct.pack("<I", s) if chksum else b""))
+
+
+def synth_mixw_from_sendump(orc, path):
+    """mixture_weights file from a sendump, as SURVEY section 0 describes: pdf = 1.0001^-(q*1024)."""
+    q = orc.ptm_mixw.astype(np.float64)                   # [feat][density][sen]
+    pdf = np.power(1.0001, -(q * 1024.0)).transpose(2, 0, 1)  # [sen][feat][density]
+    pdf = np.ascontiguousarray(pdf, dtype="<f4")
+    n_sen, n_feat, n_cw = pdf.shape
+    payload = struct.pack("<4i", n_sen, n_feat, n_cw, pdf.size) + pdf.tobytes()
+    _write_s3(path, payload)
+
+
+def test_mixture_weights_reader_matches_oracle(lib, oracle_mod, orc_fr, tmp_path):
+    """read_mixw (PTM quantisation) and senone_mixw_read (ms quantisation) from a float file."""
+    src = os.path.join(MODEL_ROOT, "fr-fr")
+    mixw = str(tmp_path / "mixture_weights")
+    synth_mixw_from_sendump(orc_fr, mixw)
+    kw = dict(mdef=os.path.join(src, "mdef"), means=os.path.join(src, "means"),
+              tmat=os.path.join(src, "transition_matrices"), mixw=mixw)
+    m = ssw.Model(variances=os.path.join(src, "variances"), config={"device": -2}, **kw)
+    o = oracle_mod.Model(vars=os.path.join(src, "variances"), **kw)
+    assert m.has_ms and m.has_ptm and o.has_ms_pdf
+    assert m.table("ms_pdf").tobytes() == o.ms_pdf.tobytes()
+    assert m.table("ptm_mixw").tobytes() == o.ptm_mixw.tobytes()
+    # quantising the synthesised weights reproduces the sendump codes almost everywhere
+    same = (o.ptm_mixw == orc_fr.ptm_mixw).mean()
+    assert same > 0.9
+
+
+def test_corrupt_model_is_refused(lib, tmp_path):
+    src = os.path.join(MODEL_ROOT, "en-us")
+    blob = bytearray(open(os.path.join(src, "variances"), "rb").read())
+    blob[-64] ^= 1
+    bad = tmp_path / "variances"
+    bad.write_bytes(bytes(blob))
+    with pytest.raises(ssw.SswError, match="checksum"):
+        ssw.Model(mdef=os.path.join(src, "mdef"), means=os.path.join(src, "means"),
+                  variances=str(bad), sendump=os.path.join(src, "sendump"),
+                  tmat=os.path.join(src, "transition_matrices"), config={"device": -2})
+    with pytest.raises(ssw.SswError):
+        ssw.Model(mdef=os.path.join(src, "nope"), means=os.path.join(src, "means"),
+                  variances=os.path.join(src, "variances"), config={"device": -2})
+
+
+def test_compute_fails_loudly_without_gpu(lib):
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    with pytest.raises(ssw.SswError, match="no HIP device|no CPU fallback"):
+        ssw.Model(os.path.join(MODEL_ROOT, "en-us"))
+    m = ssw.Model(os.path.join(MODEL_ROOT, "en-us"), config={"device": -2})
+    with pytest.raises(ssw.SswError, match="no CPU fallback"):
+        m.score_batch(np.zeros((4, 39), np.float32))
+    with pytest.raises(ssw.SswError, match="no CPU fallback"):
+        m.align_batch(0, [0, 1], [0, 1], np.zeros((1, 3), np.uint16), np.zeros(1, np.int16))
+    with pytest.raises(ssw.SswError):
+        ssw.PtmMgau(m)
+
+
+def test_alignment_propagate_matches_reference_loop(lib):
+    """ssw_alignment_propagate == the loops of src/ps_alignment.c:316-352."""
+    m = ssw.Model(os.path.join(MODEL_ROOT, "en-us"), config={"device": -2})
+    rng = np.random.default_rng(3)
+    st = np.stack([np.arange(12) * 2, np.full(12, 2), rng.integers(-500, 0, 12)], 1).astype(np.int32)
+    ph = m.propagate(st, np.arange(12) // 3, 4)
+    assert ph[:, 0].tolist() == [0, 6, 12, 18] and ph[:, 1].tolist() == [6] * 4
+    assert ph[:, 2].tolist() == st[:, 2].reshape(4, 3).sum(1).tolist()
+    words = m.propagate(ph, [0, 0, 1, 1], 2)
+    assert words.tolist() == [[0, 12, int(ph[:2, 2].sum())], [12, 12, int(ph[2:, 2].sum())]]
+    with pytest.raises(ssw.SswError):
+        m.propagate(st, np.full(12, 9), 4)
+
+
+def test_synthetic_feature_generator_is_pinned(means_en):
+    """The LCG and feature recipe of SURVEY 8(d); first values fixed here so both sides of every
+    parity test keep seeing the same inputs."""
+    from soundswallower_amd.synth import lcg_uniform, synth_features
+    u = lcg_uniform(12345, 3)
+    s = 12345
+    ref = []
+    for _ in range(3):
+        s = (s * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        ref.append(((s >> 11) & ((1 << 53) - 1)) / float(1 << 53))
+    assert u.tolist() == ref
+    f = synth_features(means_en, 4, 12345)
+    assert f.shape == (4, 39) and f.dtype == np.float32
+    cb, cw = int(np.floor(ref[0] * 42)), int(np.floor(ref[1] * 128))
+    assert abs(float(f[0, 0]) - float(means_en[cb, 0, cw, 0])) <= 0.25
