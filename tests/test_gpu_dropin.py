@@ -1,0 +1,134 @@
+"""GPU: the vtable-shaped objects behave like the reference objects they stand in for."""
+import numpy as np
+import pytest
+
+import soundswallower_amd as ssw
+from soundswallower_amd.synth import lcg_uniform, synth_alignment_task, synth_features
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mgau_vtable_frame_by_frame_matches_reference_semantics(gpu_en, orc_en, means_en):
+    """ptm_mgau_frame_eval driven as acmod drives it: frame_idx written from outside, history
+    carried from frame to frame AND across utterances (no reset), past frames re-scored from the
+    stored top-N (src/ptm_mgau.c:425-448, src/acmod.c:367,760)."""
+    g = ssw.PtmMgau(gpu_en)
+    assert g.name == "ptm"
+    assert g.transform() == -1
+    orc_en.ptm_reset()
+    for utt in range(2):                      # second utterance starts from the carried history
+        feats = synth_features(means_en, 9, 500 + utt)
+        g.frame_idx = 0
+        orc_en.ptm_set_frame_idx(0)
+        for t in range(len(feats)):
+            got = g.frame_eval(feats[t], t)
+            ref = orc_en.ptm_frame_eval(feats[t], t)
+            assert np.array_equal(got, ref), (utt, t)
+            if t == 4:                        # re-score a past frame: features are ignored
+                g.frame_idx = t + 1
+                orc_en.ptm_set_frame_idx(t + 1)
+                again = g.frame_eval(np.zeros(39, np.float32), t)
+                assert np.array_equal(again, ref)
+            g.frame_idx = t + 1               # acmod_advance
+            orc_en.ptm_set_frame_idx(t + 1)
+    with pytest.raises(ssw.SswError, match="compallsen"):
+        g.frame_eval(feats[0], 0, compallsen=False, senone_active=np.zeros(1, np.uint8))
+    g.free()
+
+
+def test_mgau_prescore_then_row_copies(gpu_en, orc_en, means_en):
+    g = ssw.PtmMgau(gpu_en)
+    feats = synth_features(means_en, 50, 77)
+    g.prescore(feats)
+    ref = orc_en.ptm_score_utt(feats)
+    for t in (0, 17, 49):
+        assert np.array_equal(g.frame_eval(feats[t], t), ref[t])
+    g.free()
+
+
+def test_state_align_search_object(gpu_en, orc_en, means_en):
+    """init/start/step/finish as decoder_alignment drives them (src/decoder.c:777-795)."""
+    n_ph, n_fr = 9, 80
+    senid, tmat, ssid = synth_alignment_task(orc_en.sseq, orc_en.phone_ssid, orc_en.phone_tmat,
+                                             orc_en.n_ciphone, n_ph, 31)
+    feats = synth_features(means_en, n_fr, 31)
+    g = ssw.PtmMgau(gpu_en)
+    s = ssw.StateAlignSearch(gpu_en, g, ssid, tmat)
+    s.start()
+    with pytest.raises(ssw.SswError, match="out of order"):
+        s.step(feats[1], 1)
+    for t in range(n_fr):
+        s.step(feats[t], t)
+    s.finish()
+    scr = orc_en.ptm_score_utt(feats)
+    rv, rst, rph = orc_en.state_align(scr, senid, tmat)
+    assert rv == 0
+    assert np.array_equal(s.states(), rst)
+    assert np.array_equal(s.phones(), rph)
+    s.free()
+    g.free()
+
+
+def test_state_align_failure_message(gpu_en, orc_en, means_en):
+    senid, tmat, ssid = synth_alignment_task(orc_en.sseq, orc_en.phone_ssid, orc_en.phone_tmat,
+                                             orc_en.n_ciphone, 10, 3)
+    feats = synth_features(means_en, 6, 3)
+    s = ssw.StateAlignSearch(gpu_en, None, ssid, tmat)
+    s.start()
+    for t in range(6):
+        s.step(feats[t], t)
+    with pytest.raises(ssw.SswError, match="Failed to reach final state"):
+        s.finish()
+
+
+def test_align_batch_ragged_with_constraints(gpu_en, orc_en):
+    """Several utterances of different shapes in one launch, word windows (sf/ef) on one."""
+    shapes = [(3, 30), (70, 400), (1, 1), (20, 25), (130, 500)]
+    frame_off, phone_off = [0], [0]
+    senids, tmats, sfs, efs, scrs, refs = [], [], [], [], [], []
+    for i, (n_ph, n_fr) in enumerate(shapes):
+        senid, tmat, _ = synth_alignment_task(orc_en.sseq, orc_en.phone_ssid, orc_en.phone_tmat,
+                                              orc_en.n_ciphone, n_ph, 1000 + i)
+        scr = np.floor(lcg_uniform(2000 + i, n_fr * orc_en.n_sen).reshape(n_fr, -1) * 700).astype(
+            np.int16)
+        sf = np.zeros(n_ph, np.int32)
+        ef = np.full(n_ph, 2**31 - 1, np.int32)
+        if i == 1:
+            sf[35:] = 200
+            ef[:35] = 200
+        refs.append(orc_en.state_align(scr, senid, tmat, sf=sf, ef=ef))
+        senids.append(senid); tmats.append(tmat); sfs.append(sf); efs.append(ef); scrs.append(scr)
+        frame_off.append(frame_off[-1] + n_fr)
+        phone_off.append(phone_off[-1] + n_ph)
+    d = gpu_en.to_device(np.concatenate(scrs))
+    try:
+        st, status = gpu_en.align_batch(d, frame_off, phone_off, np.concatenate(senids),
+                                        np.concatenate(tmats), np.concatenate(sfs),
+                                        np.concatenate(efs))
+    finally:
+        gpu_en.device_free(d)
+    for i, (rv, rst, _) in enumerate(refs):
+        assert (status[i] == 0) == (rv == 0), i
+        if rv == 0:
+            assert np.array_equal(st[phone_off[i] * 3:phone_off[i + 1] * 3], rst), i
+    assert status[2] != 0 or shapes[2] == (1, 1)
+
+
+def test_renormalisation_path(gpu_en, orc_en):
+    """Scores large enough to trip `best_score - 0x300000 < WORST_SCORE`
+    (src/state_align_search.c:193-197) on a long utterance."""
+    n_ph, n_fr = 4, 17500
+    senid, tmat, _ = synth_alignment_task(orc_en.sseq, orc_en.phone_ssid, orc_en.phone_tmat,
+                                          orc_en.n_ciphone, n_ph, 77)
+    scr = np.full((n_fr, orc_en.n_sen), 32000, np.int16)
+    scr[:, ::7] = 31000
+    rv, rst, _, trace = orc_en.state_align(scr, senid, tmat, want_trace=True)
+    assert trace.min() - 0x300000 < -536870912, "test must actually reach the renormalisation"
+    d = gpu_en.to_device(scr)
+    try:
+        st, status = gpu_en.align_batch(d, [0, n_fr], [0, n_ph], senid, tmat)
+    finally:
+        gpu_en.device_free(d)
+    assert (status[0] == 0) == (rv == 0)
+    if rv == 0:
+        assert np.array_equal(st, rst)
