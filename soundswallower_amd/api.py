@@ -294,3 +294,14 @@ class StateAlignSearch:
             self._s = None
 
     __del__ = free
+
+
+class MsMgau(PtmMgau):
+    """`mgau_t` stand-in created by ssw_ms_mgau_init (the "ms" scorer)."""
+
+    def __init__(self, model: Model):
+        self._L = _lib.lib()
+        self.model = model
+        self._g = self._L.ssw_ms_mgau_init(model._m)
+        if not self._g:
+            raise SswError("ssw_ms_mgau_init: " + _lib.last_error())

@@ -56,6 +56,15 @@ dens2int(float d)
     return d < -2147483648.0f ? INT_MIN : (int)d;
 }
 
+/* senone_eval's density term (src/ms_senone.c:332-335): INT32_MIN >> 10 below the int range,
+ * else ((int32)dist + 1023) >> 10 */
+__device__ __forceinline__ int
+ms_fden(float d)
+{
+    return d < -2147483648.0f ? (INT_MIN >> SSW_SENSCR_SHIFT)
+                              : (((int)d + ((1 << SSW_SENSCR_SHIFT) - 1)) >> SSW_SENSCR_SHIFT);
+}
+
 /* d = det - sum_j (x_j - mu_j)^2 v_j: sub, mul, mul, sub, each rounded, j ascending
  * (src/ptm_mgau.c:63-68, src/ms_gauden.c:410-416). */
 template <int VECLEN>
@@ -436,7 +445,7 @@ med3f(float a, float b, float c)
     return __builtin_amdgcn_fmed3f(a, b, c);
 }
 
-template <int VECLEN, int FPL>
+template <int VECLEN, int FPL, bool MS>
 __global__ void __launch_bounds__(256)
 ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ feats,
                        FramesParams P)
@@ -547,6 +556,7 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
 #pragma unroll
     for (int h = 0; h < FPL; ++h) {
         int c[4], s[4];
+        float dv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             c[k] = (int)(__float_as_uint(L[h][k]) & 127u);
@@ -568,17 +578,23 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
                 float cc = sq * buf[SSW_REC_VAR + j];
                 dd = dd - cc;
             }
-            s[k] = dens2int(dd);
+            dv[k] = dd;
+            /* PTM keeps the truncated density (src/ptm_mgau.c:128-131); the ms scorer keeps the
+             * float and later uses ((int32)dist + 1023) >> 10 (src/ms_senone.c:332-335) */
+            s[k] = MS ? ms_fden(dd) : dens2int(dd);
         }
-        /* sort the four (score, cw) pairs, best first */
+        /* sort the four best first: PTM by truncated score, ms by the float itself */
 #define CSWAP(a, b)                                                                          \
     {                                                                                        \
-        bool sw = s[b] > s[a];                                                               \
+        bool sw = MS ? (dv[b] > dv[a]) : (s[b] > s[a]);                                      \
         int ts = sw ? s[b] : s[a], tc = sw ? c[b] : c[a];                                    \
+        float td = sw ? dv[b] : dv[a];                                                       \
         s[b] = sw ? s[a] : s[b];                                                             \
         c[b] = sw ? c[a] : c[b];                                                             \
+        dv[b] = sw ? dv[a] : dv[b];                                                          \
         s[a] = ts;                                                                           \
         c[a] = tc;                                                                           \
+        dv[a] = td;                                                                          \
     }
         CSWAP(0, 1) CSWAP(2, 3) CSWAP(0, 2) CSWAP(1, 3) CSWAP(1, 2)
 #undef CSWAP
@@ -586,8 +602,11 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
          * its 7 borrowed bits pushed towards +inf */
         uint32_t kb = __float_as_uint(L[h][4]);
         float ub = __uint_as_float((kb & 0x80000000u) ? (kb & ~127u) : (kb | 127u));
-        int irest = dens2int(ub);
-        bool proven = s[0] > s[1] && s[1] > s[2] && s[2] > s[3] && s[3] > irest;
+        bool proven;
+        if (MS) /* compute_dist orders by float; exact ties are what needs the exact pass */
+            proven = dv[0] > dv[1] && dv[1] > dv[2] && dv[2] > dv[3] && dv[3] > ub;
+        else
+            proven = s[0] > s[1] && s[1] > s[2] && s[2] > s[3] && s[3] > dens2int(ub);
         if (tt[h] < P.n_frames) {
             size_t idx = (size_t)tt[h] * P.n_cbf + cbf;
             P.topn_cw[idx] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16)
@@ -597,6 +616,119 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
                 atomicOr(&P.flags[idx >> 5], 1u << (idx & 31));
         }
     }
+}
+
+/* Exact pass of the ms scorer for flagged pairs: compute_dist (src/ms_gauden.c:384-432) is
+ * history-free, so every flagged (frame, codebook, stream) is independent.  The list starts at
+ * dist = (float)INT32_MIN; codeword d is admitted when dval >= worst.dist and placed at the
+ * first position i with dval >= dist[i]. */
+template <int VECLEN, int NDL, int TOPN>
+__global__ void __launch_bounds__(64)
+ms_topn_fixup_kernel(ChainParams P, int n_words, unsigned long long *n_fixed)
+{
+    const int lane = threadIdx.x;
+    float mean[NDL][VECLEN], var[NDL][VECLEN], det[NDL];
+    int loaded_cbf = -1;
+    unsigned long long fixed = 0;
+    constexpr int WPW = 8;
+    for (int chunk = blockIdx.x; chunk * WPW < n_words; chunk += gridDim.x) {
+        int widx = chunk * WPW + lane;
+        uint32_t word = (lane < WPW && widx < n_words) ? P.flags[widx] : 0u;
+        unsigned long long wmask = __ballot(word != 0);
+        while (wmask) {
+            int l = __builtin_ctzll(wmask);
+            wmask &= wmask - 1;
+            uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)word, l);
+            while (w) {
+                int b = __builtin_ctz(w);
+                w &= w - 1;
+                long long bit = ((long long)(chunk * WPW + l) << 5) + b;
+                int t = (int)(bit / P.n_cbf);
+                int cbf = (int)(bit - (long long)t * P.n_cbf);
+                if (cbf != loaded_cbf) {
+                    load_lane_gaussians<VECLEN, NDL>(
+                        P.rec + (size_t)cbf * (NDL * 64) * SSW_REC_FLOATS, lane, mean, var, det);
+                    loaded_cbf = cbf;
+                }
+                const int f = cbf % P.n_feat;
+                const float *xp = P.feats + (size_t)t * P.featdim + P.featoff[f];
+                float x[VECLEN];
+#pragma unroll
+                for (int j = 0; j < VECLEN; ++j)
+                    x[j] = xp[j];
+                float dvl[NDL];
+#pragma unroll
+                for (int h = 0; h < NDL; ++h)
+                    dvl[h] = density<VECLEN>(x, mean[h], var[h], det[h]);
+                float Ld[TOPN];
+                int Lc[TOPN];
+#pragma unroll
+                for (int k = 0; k < TOPN; ++k) {
+                    Ld[k] = -2147483648.0f;
+                    Lc[k] = 0;
+                }
+                unsigned long long rem[NDL];
+#pragma unroll
+                for (int h = 0; h < NDL; ++h)
+                    rem[h] = ~0ull;
+                for (;;) {
+                    float thr = Ld[TOPN - 1];
+                    int cw = -1;
+#pragma unroll
+                    for (int h = NDL - 1; h >= 0; --h) {
+                        unsigned long long m = __ballot(dvl[h] >= thr) & rem[h];
+                        if (m != 0)
+                            cw = h * 64 + __builtin_ctzll(m);
+                    }
+                    if (cw < 0)
+                        break;
+#pragma unroll
+                    for (int h = 0; h < NDL; ++h) {
+                        if (h < (cw >> 6))
+                            rem[h] = 0;
+                        else if (h == (cw >> 6))
+                            rem[h] &= ~((2ull << (cw & 63)) - 1ull);
+                    }
+                    float dval = 0.0f;
+#pragma unroll
+                    for (int h = 0; h < NDL; ++h) {
+                        float tv = __builtin_bit_cast(
+                            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dvl[h]),
+                                                             cw & 63));
+                        dval = ((cw >> 6) == h) ? tv : dval;
+                    }
+                    int pos = 0;
+#pragma unroll
+                    for (int k = 0; k < TOPN - 1; ++k)
+                        pos += (Ld[k] > dval) ? 1 : 0;
+#pragma unroll
+                    for (int k = TOPN - 1; k >= 1; --k)
+                        if (k > pos) {
+                            Ld[k] = Ld[k - 1];
+                            Lc[k] = Lc[k - 1];
+                        }
+#pragma unroll
+                    for (int k = 0; k < TOPN; ++k)
+                        if (k == pos) {
+                            Ld[k] = dval;
+                            Lc[k] = cw;
+                        }
+                }
+                if (lane == 0) {
+                    uint32_t pk = 0;
+#pragma unroll
+                    for (int k = 0; k < TOPN; ++k)
+                        pk |= (uint32_t)(Lc[k] & 0xff) << (8 * k);
+                    P.topn_cw[(size_t)t * P.n_cbf + cbf] = pk;
+                    P.topn_sc[(size_t)t * P.n_cbf + cbf]
+                        = make_int4(ms_fden(Ld[0]), ms_fden(Ld[1]), ms_fden(Ld[2]), ms_fden(Ld[3]));
+                }
+                ++fixed;
+            }
+        }
+    }
+    if (lane == 0 && fixed)
+        atomicAdd(n_fixed, fixed);
 }
 
 /* ---------------------------------------------------------------------------------- */
@@ -614,6 +746,7 @@ struct SenoneParams {
     unsigned long long *nfixed; /* optional: [0] running count of the fix-up pass, [1] last batch */
     int16_t *out;            /* [n_frames][n_sen] */
     int n_frames, n_cb, n_feat, n_density, n_sen, slot_stride, n_quads;
+    int aw, zero; /* ms scorer: acoustic weight divisor, logmath zero at shift 10 */
 };
 
 constexpr int SEN_MAX_THREADS = 1024;
@@ -765,6 +898,141 @@ ptm_senone_kernel(SenoneParams P)
             for (int j = 0; j < 4; ++j)
                 if (sj[j] >= 0) /* int16 arithmetic as in src/ptm_mgau.c:394-400 */
                     orow[sj[j]] = (int16_t)((int16_t)asc[r][j] - (int16_t)best);
+        }
+    }
+}
+
+/* logmath_add on the shift-10 table (src/logmath.c:228-272): max(x, y) + table[|x - y|], with
+ * the "zero" short-cuts; the table has exactly 256 entries for the bases the loader accepts. */
+__device__ __forceinline__ int
+ms_logadd(int x, int y, int zero, const uint8_t *tab)
+{
+    int d = x > y ? x - y : y - x;
+    int r = x > y ? x : y;
+    int add = d < 256 ? (int)tab[d < 256 ? d : 255] : 0;
+    int v = r + add;
+    v = (y <= zero) ? x : v;
+    v = (x <= zero) ? y : v;
+    return v;
+}
+
+/* K3b: senone_eval + frame normalisation of the ms scorer (src/ms_senone.c:314-362,
+ * src/ms_mgau.c:299-321).  Same slot order and quad-per-lane layout as ptm_senone_kernel; the
+ * top-N block holds fden = ((int32)dist + 1023) >> 10 per codeword. */
+template <int R>
+__global__ void __launch_bounds__(SEN_MAX_THREADS)
+ms_senone_kernel(SenoneParams P)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n_cbf = P.n_cb * P.n_feat;
+    /* LDS carve: logadd[256] | fd[n_cbf] int4 | cw4[n_cbf] | red[16] */
+    uint8_t *s_tab = smem;
+    int4 *s_fd = reinterpret_cast<int4 *>(smem + 256);
+    uint32_t *s_cw4 = reinterpret_cast<uint32_t *>(s_fd + n_cbf);
+    int *s_red = reinterpret_cast<int *>(s_cw4 + n_cbf);
+
+    const int t = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    if (tid < 256)
+        s_tab[tid] = P.logadd8[tid];
+    if (tid < n_cbf) {
+        s_fd[tid] = P.topn_sc[(size_t)t * n_cbf + tid];
+        s_cw4[tid] = P.topn_cw[(size_t)t * n_cbf + tid];
+    }
+    if (P.flags != nullptr) {
+        long long b0 = (long long)t * n_cbf, b1 = b0 + n_cbf - 1;
+        int w0 = (int)(b0 >> 5), w1 = (int)(b1 >> 5);
+        if (tid <= w1 - w0)
+            P.flags[w0 + tid] = 0u;
+        if (t == 0 && tid == 0) {
+            P.nfixed[1] = P.nfixed[0];
+            P.nfixed[0] = 0ull;
+        }
+    }
+    __syncthreads();
+
+    int scr[R][4];
+    int best = INT_MAX;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int q = r * nthr + tid;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            scr[r][j] = 0;
+        if (q < P.n_quads) {
+            const int cb = P.quad_cb[q];
+            const uint8_t *mq = P.mixw + (size_t)q * 4;
+            for (int f = 0; f < P.n_feat; ++f) {
+                const uint32_t cw4 = s_cw4[cb * P.n_feat + f];
+                const int4 fd4 = s_fd[cb * P.n_feat + f];
+                const int fd[4] = { fd4.x, fd4.y, fd4.z, fd4.w };
+                uint32_t mw[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t cw = (cw4 >> (8 * k)) & 0xffu;
+                    mw[k] = *reinterpret_cast<const uint32_t *>(
+                        mq + ((size_t)f * P.n_density + cw) * P.slot_stride);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int fscr = fd[0] - (int)((mw[0] >> (8 * j)) & 0xffu);
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) {
+                        int fw = fd[k] - (int)((mw[k] >> (8 * j)) & 0xffu);
+                        fscr = ms_logadd(fscr, fw, P.zero, s_tab);
+                    }
+                    scr[r][j] -= fscr;
+                }
+            }
+            const short4 sen = P.slot_sen[q];
+            const int sj[4] = { sen.x, sen.y, sen.z, sen.w };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int v = scr[r][j] / P.aw; /* C division truncates toward zero */
+                v = v > 32767 ? 32767 : v;
+                v = v < -32768 ? -32768 : v;
+                scr[r][j] = v;
+                if (sj[j] >= 0)
+                    best = v < best ? v : best;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        int o = __shfl_xor(best, off, WAVE);
+        best = o < best ? o : best;
+    }
+    if ((tid & 63) == 0)
+        s_red[tid >> 6] = best;
+    __syncthreads();
+    if (tid < 64) {
+        int b = tid < (nthr >> 6) ? s_red[tid] : INT_MAX;
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            int o = __shfl_xor(b, off, WAVE);
+            b = o < b ? o : b;
+        }
+        if (tid == 0)
+            s_red[0] = b;
+    }
+    __syncthreads();
+    best = s_red[0];
+    int16_t *orow = P.out + (size_t)t * P.n_sen;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int q = r * nthr + tid;
+        if (q < P.n_quads) {
+            const short4 sen = P.slot_sen[q];
+            const int sj[4] = { sen.x, sen.y, sen.z, sen.w };
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (sj[j] >= 0) {
+                    int bs = scr[r][j] - best; /* src/ms_mgau.c:314-320 */
+                    bs = bs > 32767 ? 32767 : bs;
+                    bs = bs < -32768 ? -32768 : bs;
+                    orow[sj[j]] = (int16_t)bs;
+                }
         }
     }
 }
@@ -1074,7 +1342,7 @@ struct ssw_model_s {
     int device;
     int n_cbf, sen_stride;
     float *d_rec;
-    uint8_t *d_mixw, *d_sen2cb, *d_logadd8, *d_tp, *d_quad_cb;
+    uint8_t *d_mixw, *d_ms_pdf, *d_sen2cb, *d_logadd8, *d_tp, *d_quad_cb;
     short4 *d_slot_sen;
     int n_quads, slot_stride;
     /* scoring workspace */
@@ -1138,7 +1406,7 @@ upload_model(ssw_model_s *m)
         HIP_OK(hipMalloc((void **)&m->d_sen2cb, s2c.size()));
         HIP_OK(hipMemcpy(m->d_sen2cb, s2c.data(), s2c.size(), hipMemcpyHostToDevice));
     }
-    if (h->ptm_mixw) {
+    if (h->ptm_mixw || h->ms_pdf) {
         /* slot order: senones grouped by codebook (ascending id inside a group), every group
          * padded to a multiple of 4 slots */
         std::vector<int16_t> slot_sen;
@@ -1156,13 +1424,29 @@ upload_model(ssw_model_s *m)
         m->n_quads = (int)quad_cb.size();
         m->slot_stride = ((int)slot_sen.size() + 127) & ~127;
         m->sen_stride = m->slot_stride;
-        std::vector<uint8_t> mw((size_t)h->n_feat * h->n_density * m->slot_stride, 0);
-        for (int r = 0; r < h->n_feat * h->n_density; ++r)
-            for (size_t sl = 0; sl < slot_sen.size(); ++sl)
-                if (slot_sen[sl] >= 0)
-                    mw[(size_t)r * m->slot_stride + sl] = h->ptm_mixw[(size_t)r * h->n_sen + slot_sen[sl]];
-        HIP_OK(hipMalloc((void **)&m->d_mixw, mw.size()));
-        HIP_OK(hipMemcpy(m->d_mixw, mw.data(), mw.size(), hipMemcpyHostToDevice));
+        const size_t rows = (size_t)h->n_feat * h->n_density;
+        if (h->ptm_mixw) {
+            std::vector<uint8_t> mw(rows * m->slot_stride, 0);
+            for (size_t r = 0; r < rows; ++r)
+                for (size_t sl = 0; sl < slot_sen.size(); ++sl)
+                    if (slot_sen[sl] >= 0)
+                        mw[r * m->slot_stride + sl] = h->ptm_mixw[r * h->n_sen + slot_sen[sl]];
+            HIP_OK(hipMalloc((void **)&m->d_mixw, mw.size()));
+            HIP_OK(hipMemcpy(m->d_mixw, mw.data(), mw.size(), hipMemcpyHostToDevice));
+        }
+        if (h->ms_pdf) {
+            /* pdf[sen][feat][cw] (src/ms_senone.c:145-148) transposed to [feat][cw][slot] */
+            std::vector<uint8_t> mw(rows * m->slot_stride, 0);
+            for (size_t sl = 0; sl < slot_sen.size(); ++sl) {
+                if (slot_sen[sl] < 0)
+                    continue;
+                const uint8_t *src = h->ms_pdf + (size_t)slot_sen[sl] * rows;
+                for (size_t r = 0; r < rows; ++r)
+                    mw[r * m->slot_stride + sl] = src[r];
+            }
+            HIP_OK(hipMalloc((void **)&m->d_ms_pdf, mw.size()));
+            HIP_OK(hipMemcpy(m->d_ms_pdf, mw.data(), mw.size(), hipMemcpyHostToDevice));
+        }
         HIP_OK(hipMalloc((void **)&m->d_quad_cb, quad_cb.size()));
         HIP_OK(hipMemcpy(m->d_quad_cb, quad_cb.data(), quad_cb.size(), hipMemcpyHostToDevice));
         HIP_OK(hipMalloc((void **)&m->d_slot_sen, slot_sen.size() * sizeof(int16_t)));
@@ -1241,6 +1525,7 @@ ssw_model_free(ssw_model_t *m)
     }
     (void)hipFree(m->d_rec);
     (void)hipFree(m->d_mixw);
+    (void)hipFree(m->d_ms_pdf);
     (void)hipFree(m->d_sen2cb);
     (void)hipFree(m->d_quad_cb);
     (void)hipFree(m->d_slot_sen);
@@ -1353,7 +1638,7 @@ ensure_score_ws(ssw_model_s *m, int n_frames, int n_utts)
 }
 
 static int
-check_ptm_shape(const ssw_model_s *m)
+check_scorer_shape(const ssw_model_s *m, int scorer)
 {
     const ssw_host_model_t *h = m->h;
     if (m->device == SSW_DEVICE_NONE) {
@@ -1361,8 +1646,21 @@ check_ptm_shape(const ssw_model_s *m)
                       "no scoring -- there is no CPU fallback");
         return -1;
     }
-    if (h->ptm_mixw == NULL) {
+    if (scorer == SSW_SCORER_PTM && h->ptm_mixw == NULL) {
         ssw_set_error("model has no PTM mixture weights (sendump / mixw)");
+        return -1;
+    }
+    if (scorer == SSW_SCORER_MS && h->ms_pdf == NULL) {
+        ssw_set_error("the ms scorer needs a mixture_weights file (src/ms_mgau.c:208-212)");
+        return -1;
+    }
+    if (scorer == SSW_SCORER_MS && (h->logadd8_size != 256 || h->cfg.aw == 0)) {
+        ssw_set_error("ms scorer: unsupported log base (add table of %d entries) or aw = 0",
+                      h->logadd8_size);
+        return -1;
+    }
+    if (scorer != SSW_SCORER_PTM && scorer != SSW_SCORER_MS) {
+        ssw_set_error("unknown scorer %d", scorer);
         return -1;
     }
     if (h->n_density != 128 || h->cfg.topn != 4 || h->n_cb > 255) {
@@ -1398,14 +1696,16 @@ fill_chain_params(const ssw_model_s *m, ChainParams &P, const float *d_feats)
 }
 
 static int
-launch_senone(ssw_model_s *m, int n_frames, const uint32_t *cw, const int4 *sc, int16_t *d_out,
-              uint32_t *flags, hipStream_t st)
+launch_senone(ssw_model_s *m, int scorer, int n_frames, const uint32_t *cw, const int4 *sc,
+              int16_t *d_out, uint32_t *flags, hipStream_t st)
 {
     const ssw_host_model_t *h = m->h;
     SenoneParams S;
     S.topn_cw = cw;
     S.topn_sc = sc;
-    S.mixw = m->d_mixw;
+    S.mixw = scorer == SSW_SCORER_MS ? m->d_ms_pdf : m->d_mixw;
+    S.aw = h->cfg.aw;
+    S.zero = h->zero8;
     S.quad_cb = m->d_quad_cb;
     S.slot_sen = m->d_slot_sen;
     S.logadd8 = m->d_logadd8;
@@ -1429,6 +1729,20 @@ launch_senone(ssw_model_s *m, int n_frames, const uint32_t *cw, const int4 *sc, 
     if (threads > SEN_MAX_THREADS) {
         ssw_set_error("too many codebook x stream pairs (%d)", m->n_cbf);
         return -1;
+    }
+    if (scorer == SSW_SCORER_MS) {
+        lds = 256 + 20 * (size_t)m->n_cbf + 16 * sizeof(int);
+        switch (R) {
+        case 1: hipLaunchKernelGGL((ms_senone_kernel<1>), dim3(n_frames), dim3(threads), lds, st, S); break;
+        case 2: hipLaunchKernelGGL((ms_senone_kernel<2>), dim3(n_frames), dim3(threads), lds, st, S); break;
+        case 3: hipLaunchKernelGGL((ms_senone_kernel<3>), dim3(n_frames), dim3(threads), lds, st, S); break;
+        case 4: hipLaunchKernelGGL((ms_senone_kernel<4>), dim3(n_frames), dim3(threads), lds, st, S); break;
+        default:
+            ssw_set_error("too many senones (%d quads)", m->n_quads);
+            return -1;
+        }
+        HIP_OK(hipGetLastError());
+        return 0;
     }
     switch (R) {
     case 1: hipLaunchKernelGGL((ptm_senone_kernel<4, 1>), dim3(n_frames), dim3(threads), lds, st, S); break;
@@ -1460,12 +1774,9 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
             ssw_set_error("utterance offsets must be non-decreasing");
             return -1;
         }
-    if (scorer != SSW_SCORER_PTM) {
-        ssw_set_error("scorer %d not available in this build", scorer);
+    if (check_scorer_shape(m, scorer) < 0)
         return -1;
-    }
-    if (check_ptm_shape(m) < 0)
-        return -1;
+    const bool ms = scorer == SSW_SCORER_MS;
     HIP_OK(hipSetDevice(m->device));
     if (ensure_score_ws(m, n_frames, n_utts) < 0)
         return -1;
@@ -1488,7 +1799,7 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
     const int64_t pairs = (int64_t)n_frames * m->n_cbf;
     if (m->timing)
         HIP_OK(hipEventRecord(m->ev[0], st));
-    if (h->cfg.ds != 1 || m->force_exact) {
+    if (!ms && (h->cfg.ds != 1 || m->force_exact)) {
         /* frame down-sampling makes every frame depend on its predecessor: exact chains */
         int n_chain = n_utts * m->n_cbf;
         hipLaunchKernelGGL((ptm_topn_chain_kernel<13, 2, 4>), dim3((n_chain + 3) / 4),
@@ -1516,23 +1827,33 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
         const int fpl = two ? 2 : 1;
         const int tiles = (n_frames + 64 * fpl - 1) / (64 * fpl);
         dim3 grid((tiles + 3) / 4, m->n_cbf);
-        if (two)
-            hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 2>), grid, dim3(256), 0, st, m->d_rec,
-                               d_feats, F);
+        if (two && ms)
+            hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 2, true>), grid, dim3(256), 0, st,
+                               m->d_rec, d_feats, F);
+        else if (two)
+            hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 2, false>), grid, dim3(256), 0, st,
+                               m->d_rec, d_feats, F);
+        else if (ms)
+            hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 1, true>), grid, dim3(256), 0, st,
+                               m->d_rec, d_feats, F);
         else
-            hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 1>), grid, dim3(256), 0, st, m->d_rec,
-                               d_feats, F);
+            hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 1, false>), grid, dim3(256), 0, st,
+                               m->d_rec, d_feats, F);
         HIP_OK(hipGetLastError());
         int fix_blocks = (n_words + 7) / 8;
         fix_blocks = fix_blocks > 8192 ? 8192 : fix_blocks;
-        hipLaunchKernelGGL((ptm_topn_fixup_kernel<13, 2, 4>), dim3(fix_blocks), dim3(64), 0, st,
-                           P, n_words, m->d_nfixed);
+        if (ms)
+            hipLaunchKernelGGL((ms_topn_fixup_kernel<13, 2, 4>), dim3(fix_blocks), dim3(64), 0,
+                               st, P, n_words, m->d_nfixed);
+        else
+            hipLaunchKernelGGL((ptm_topn_fixup_kernel<13, 2, 4>), dim3(fix_blocks), dim3(64), 0,
+                               st, P, n_words, m->d_nfixed);
         HIP_OK(hipGetLastError());
         m->stats_pending = 1;
     }
     if (m->timing)
         HIP_OK(hipEventRecord(m->ev[1], st));
-    if (launch_senone(m, n_frames, m->d_topn_cw, m->d_topn_sc, d_out,
+    if (launch_senone(m, scorer, n_frames, m->d_topn_cw, m->d_topn_sc, d_out,
                       m->stats_pending ? m->d_flags : NULL, st) < 0)
         return -1;
     if (m->timing)
@@ -1549,7 +1870,7 @@ ssw_score_batch_host(ssw_model_t *m, int scorer, const float *feats, int32_t n_f
     const ssw_host_model_t *h = m->h;
     if (n_frames <= 0)
         return 0;
-    if (scorer == SSW_SCORER_PTM && check_ptm_shape(m) < 0)
+    if (check_scorer_shape(m, scorer) < 0)
         return -1;
     HIP_OK(hipSetDevice(m->device));
     if ((size_t)n_frames > m->st_frames) {
@@ -1813,7 +2134,7 @@ mgau_reset_device_hist(ssw_mgau_impl *g)
 extern "C" ssw_mgau_t *
 ssw_ptm_mgau_init(ssw_model_t *m)
 {
-    if (check_ptm_shape(m) < 0)
+    if (check_scorer_shape(m, SSW_SCORER_PTM) < 0)
         return NULL;
     if (hipSetDevice(m->device) != hipSuccess) {
         ssw_set_error("hipSetDevice failed");
@@ -1848,12 +2169,37 @@ ssw_ptm_mgau_init(ssw_model_t *m)
     return &g->base;
 }
 
+static ssw_mgaufuncs_t g_ms_funcs = { "ms", mgau_frame_eval, mgau_transform, mgau_free };
+
+/* ms_mgau_init(acmod_t *) (src/ms_mgau.c:165): needs a model loaded with a mixture_weights file */
 extern "C" ssw_mgau_t *
 ssw_ms_mgau_init(ssw_model_t *m)
 {
-    (void)m;
-    ssw_set_error("the ms scorer is not built yet (SURVEY section 8, kernel 3)");
-    return NULL;
+    if (check_scorer_shape(m, SSW_SCORER_MS) < 0)
+        return NULL;
+    if (hipSetDevice(m->device) != hipSuccess) {
+        ssw_set_error("hipSetDevice failed");
+        return NULL;
+    }
+    ssw_mgau_impl *g = new ssw_mgau_impl();
+    g->base.vt = &g_ms_funcs;
+    g->base.frame_idx = 0;
+    g->m = m;
+    g->scorer = SSW_SCORER_MS;
+    g->cache_frames = 0;
+    g->d_utt1 = NULL;
+    g->d_feat1 = NULL;
+    g->d_out1 = NULL;
+    for (int i = 0; i < 2; ++i) {
+        g->d_hist_cw[i] = NULL;
+        g->d_hist_sc[i] = NULL;
+    }
+    if (dev_alloc(&g->d_feat1, (size_t)m->h->veclen_total) < 0
+        || dev_alloc(&g->d_out1, (size_t)m->h->n_sen) < 0) {
+        mgau_free(&g->base);
+        return NULL;
+    }
+    return &g->base;
 }
 
 extern "C" void
@@ -1861,7 +2207,8 @@ ssw_mgau_reset_hist(ssw_mgau_t *mg)
 {
     ssw_mgau_impl *g = reinterpret_cast<ssw_mgau_impl *>(mg);
     (void)hipSetDevice(g->m->device);
-    (void)mgau_reset_device_hist(g);
+    if (g->scorer == SSW_SCORER_PTM)
+        (void)mgau_reset_device_hist(g);
     g->cache_frames = 0;
 }
 
@@ -1904,6 +2251,17 @@ mgau_frame_eval(ssw_mgau_t *mg, int16_t *senscr, uint8_t *senone_active,
         return 0;
     }
     HIP_OK(hipSetDevice(m->device));
+    if (g->scorer == SSW_SCORER_MS) { /* history-free: one frame is a batch of one */
+        float row[SSW_MAX_FEAT * SSW_MAX_VECLEN];
+        int32_t off[2] = { 0, 1 };
+        for (int f = 0; f < h->n_feat; ++f)
+            memcpy(row + h->featoff[f], feat[f], sizeof(float) * h->veclen[f]);
+        HIP_OK(hipMemcpy(g->d_feat1, row, sizeof(float) * h->veclen_total, hipMemcpyHostToDevice));
+        if (ssw_score_batch(m, SSW_SCORER_MS, g->d_feat1, 1, off, 1, g->d_out1, NULL) < 0)
+            return -1;
+        HIP_OK(hipMemcpy(senscr, g->d_out1, sizeof(int16_t) * h->n_sen, hipMemcpyDeviceToHost));
+        return 0;
+    }
     const int slot = frame % 2;
     if (frame >= g->base.frame_idx) {
         float row[SSW_MAX_FEAT * SSW_MAX_VECLEN];
@@ -1922,7 +2280,8 @@ mgau_frame_eval(ssw_mgau_t *mg, int16_t *senscr, uint8_t *senone_active,
                            dim3(256), 0, 0, P);
         HIP_OK(hipGetLastError());
     }
-    if (launch_senone(m, 1, g->d_hist_cw[slot], g->d_hist_sc[slot], g->d_out1, NULL, 0) < 0)
+    if (launch_senone(m, SSW_SCORER_PTM, 1, g->d_hist_cw[slot], g->d_hist_sc[slot], g->d_out1, NULL,
+                      0) < 0)
         return -1;
     HIP_OK(hipMemcpy(senscr, g->d_out1, sizeof(int16_t) * h->n_sen, hipMemcpyDeviceToHost));
     return 0;

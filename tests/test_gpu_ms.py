@@ -1,0 +1,76 @@
+"""GPU parity: the ms scorer (gauden_dist + senone_eval) vs the CPU oracle, fr-fr with a
+mixture_weights file synthesised from the sendump (BASELINE config 4)."""
+import os
+
+import numpy as np
+import pytest
+
+import soundswallower_amd as ssw
+from soundswallower_amd.synth import synth_features
+from tests.conftest import MODEL_ROOT
+from tests.test_cabi_host import synth_mixw_from_sendump
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ms_models(oracle_mod, orc_fr, tmp_path_factory):
+    src = os.path.join(MODEL_ROOT, "fr-fr")
+    mixw = str(tmp_path_factory.mktemp("ms") / "mixture_weights")
+    synth_mixw_from_sendump(orc_fr, mixw)
+    kw = dict(mdef=os.path.join(src, "mdef"), means=os.path.join(src, "means"),
+              tmat=os.path.join(src, "transition_matrices"), mixw=mixw)
+    g = ssw.Model(variances=os.path.join(src, "variances"), **kw)
+    o = oracle_mod.Model(vars=os.path.join(src, "variances"), **kw)
+    return g, o
+
+
+def test_ms_small_batch_bit_exact(ms_models, means_fr):
+    g, o = ms_models
+    lens = [33, 1, 70]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    feats = np.concatenate([synth_features(means_fr, n, 12345 + i) for i, n in enumerate(lens)])
+    got = g.score_batch(feats, off, scorer=ssw.SCORER_MS)
+    ref = o.ms_score_utt(feats)
+    assert np.array_equal(got, ref)
+
+
+def test_ms_config4_8192_frames(ms_models, means_fr):
+    """BASELINE config 4: 8192 frames as 32 x 256."""
+    g, o = ms_models
+    feats = np.concatenate([synth_features(means_fr, 256, 12345 + i) for i in range(32)])
+    off = (np.arange(33) * 256).astype(np.int32)
+    got = g.score_batch(feats, off, scorer=ssw.SCORER_MS)
+    flagged, pairs = g.last_stats()
+    assert pairs == 8192 * 108
+    # the oracle needs ~1 ms per frame: check 1024 frames in full, the rest by invariants
+    ref = o.ms_score_utt(feats[:1024])
+    assert np.array_equal(got[:1024], ref)
+    assert (got.min(axis=1) == 0).all()
+
+
+def test_ms_exact_ties_take_the_exact_pass(ms_models, means_fr):
+    """A frame sitting exactly on two identical densities is impossible to build from the model,
+    but duplicated frames and extreme features must still agree with the oracle."""
+    g, o = ms_models
+    base = synth_features(means_fr, 4, 9)
+    feats = np.concatenate([np.repeat(base[:1], 5, 0), base * 50.0, -base * 1000.0])
+    got = g.score_batch(feats, scorer=ssw.SCORER_MS)
+    assert np.array_equal(got, o.ms_score_utt(feats))
+
+
+def test_ms_mgau_vtable(ms_models, means_fr):
+    g, o = ms_models
+    mg = ssw.MsMgau(g)
+    assert mg.name == "ms"
+    feats = synth_features(means_fr, 3, 1)
+    for t in range(3):
+        assert np.array_equal(mg.frame_eval(feats[t], t), o.ms_frame_eval(feats[t], t))
+    mg.free()
+
+
+def test_ptm_model_without_mixw_refuses_ms(gpu_en):
+    with pytest.raises(ssw.SswError, match="mixture_weights"):
+        gpu_en.score_batch(np.zeros((2, 39), np.float32), scorer=ssw.SCORER_MS)
+    with pytest.raises(ssw.SswError):
+        ssw.MsMgau(gpu_en)
