@@ -38,8 +38,10 @@ def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libssw_oracle.so")
     src = os.path.join(_HERE, "ssw_oracle.c")
     hdr = os.path.join(_HERE, "ssw_oracle.h")
+    fe = os.path.join(_HERE, "ssw_oracle_fe.c")
     stale = (not os.path.exists(so)
-             or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+             or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr),
+                                           os.path.getmtime(fe)))
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libssw_oracle.so"],
                               stdout=subprocess.DEVNULL)
@@ -88,6 +90,8 @@ def lib() -> C.CDLL:
     L.orc_flags2list.argtypes = [vp, C.c_int, vp]
     L.orc_state_align.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
                                   vp, vp, vp]
+    L.orc_fe_mfcc.argtypes = [vp, C.c_size_t, C.c_int, f64, f64, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.orc_feat_1s_c_d_dd.argtypes = [vp, C.c_int, vp]
     L.orc_hmm_vit_eval.restype = i32
     L.orc_hmm_vit_eval.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp]
     _LIB = L
@@ -314,3 +318,23 @@ def hmm_vit_eval(tp, senscr, senid, score, history, out_score, out_history):
     best = lib().orc_hmm_vit_eval(n_emit, _ptr(tp), _ptr(senscr), _ptr(senid), _ptr(score),
                                   _ptr(history), _ptr(out))
     return best, score, history, int(out[0]), int(out[1])
+
+
+def fe_mfcc(pcm, nfilt=40, lowerf=133.33334, upperf=6855.4976, lifter=0, remove_noise=False,
+            transform="legacy"):
+    """Whole-buffer MFCC of int16 PCM with the reference's default front end (16 kHz)."""
+    pcm = np.ascontiguousarray(pcm, np.int16)
+    max_fr = len(pcm) // 160 + 3
+    cep = np.zeros((max_fr, 13), np.float32)
+    n = lib().orc_fe_mfcc(_ptr(pcm), len(pcm), int(nfilt), float(lowerf), float(upperf),
+                          int(lifter), int(bool(remove_noise)), int(transform == "legacy"),
+                          _ptr(cep), max_fr)
+    return cep[:n].copy()
+
+
+def feat_1s_c_d_dd(cep):
+    """Batch CMN + 1s_c_d_dd dynamic features: [n][13] -> [n][39]."""
+    cep = np.ascontiguousarray(cep, np.float32).copy()
+    out = np.zeros((cep.shape[0], 39), np.float32)
+    lib().orc_feat_1s_c_d_dd(_ptr(cep), cep.shape[0], _ptr(out))
+    return out

@@ -140,6 +140,13 @@ int32_t orc_hmm_vit_eval(int n_emit, const uint8_t *tp /* [n_emit][n_emit+1] */,
                          const int16_t *senscr, const uint16_t *senid, int32_t *score,
                          int32_t *history, int32_t *out);
 
+/* ---- front end + dynamic features (oracle/ssw_oracle_fe.c): only to reproduce the
+ * reference's recorded alignment of tests/data/goforward.wav end to end ---------------------- */
+int orc_fe_mfcc(const int16_t *pcm, size_t n_samps, int nfilt, double lowerf, double upperf,
+                int lifter, int remove_noise_flag, int legacy_transform, float *cep,
+                int max_frames);
+int orc_feat_1s_c_d_dd(float *cep, int n, float *out);
+
 #ifdef __cplusplus
 }
 #endif
