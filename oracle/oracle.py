@@ -338,3 +338,21 @@ def feat_1s_c_d_dd(cep):
     out = np.zeros((cep.shape[0], 39), np.float32)
     lib().orc_feat_1s_c_d_dd(_ptr(cep), cep.shape[0], _ptr(out))
     return out
+
+
+def _bind_mdef(L):
+    L.orc_mdef_ciphone_id.argtypes = [C.c_void_p, C.c_char_p]
+    L.orc_mdef_phone_id_nearest.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+
+
+def ciphone_id(model: "Model", name: str) -> int:
+    L = lib()
+    _bind_mdef(L)
+    return L.orc_mdef_ciphone_id(model._m, name.encode())
+
+
+def phone_id_nearest(model: "Model", b: int, l: int, r: int, pos: int) -> int:
+    """bin_mdef_phone_id_nearest; pos: 0 internal, 1 begin, 2 end, 3 single."""
+    L = lib()
+    _bind_mdef(L)
+    return L.orc_mdef_phone_id_nearest(model._m, int(b), int(l), int(r), int(pos))

@@ -383,6 +383,10 @@ struct orc_model_s {
     uint16_t *sseq;
     int16_t *sen2cimap;
     int32_t *phone_ssid, *phone_tmat;
+    uint8_t *cd_tree;     /* n_cd_tree x {int16 ctx, int16 n_down, int32 pid|down}, host order */
+    uint8_t *ci_filler;   /* [n_ciphone] mdef_entry_t.info.ci.filler */
+    char *ciname;         /* NUL-separated CI phone names */
+    size_t ciname_len;
 
     /* tmat */
     uint8_t *tp; /* [n_tmat][n_emit][n_emit+1] */
@@ -587,7 +591,28 @@ load_mdef(orc_model_t *m, const char *path)
         if (p > s.len)
             goto trunc;
     }
+    m->ciname_len = p - names_start;
+    m->ciname = malloc(m->ciname_len + 1);
+    memcpy(m->ciname, s.buf + names_start, m->ciname_len);
     p = names_start + (((p - names_start) + 3) & ~(size_t)3);
+    if (p + (size_t)m->n_cd_tree * 8 > s.len)
+        goto trunc;
+    m->cd_tree = malloc((size_t)m->n_cd_tree * 8 + 8);
+    memcpy(m->cd_tree, s.buf + p, (size_t)m->n_cd_tree * 8);
+    if (s.do_swap) /* bin_mdef.c:425-431 */
+        for (i = 0; i < m->n_cd_tree; ++i) {
+            uint16_t a, b;
+            uint32_t c;
+            memcpy(&a, m->cd_tree + (size_t)i * 8, 2);
+            memcpy(&b, m->cd_tree + (size_t)i * 8 + 2, 2);
+            memcpy(&c, m->cd_tree + (size_t)i * 8 + 4, 4);
+            a = bswap16(a);
+            b = bswap16(b);
+            c = bswap32(c);
+            memcpy(m->cd_tree + (size_t)i * 8, &a, 2);
+            memcpy(m->cd_tree + (size_t)i * 8 + 2, &b, 2);
+            memcpy(m->cd_tree + (size_t)i * 8 + 4, &c, 4);
+        }
     p += (size_t)m->n_cd_tree * 8; /* cd_tree_t is 8 bytes */
     if (p + (size_t)m->n_phone * 12 + 4 > s.len)
         goto trunc;
@@ -595,6 +620,9 @@ load_mdef(orc_model_t *m, const char *path)
     m->phone_ssid = calloc(m->n_phone, sizeof(int32_t));
     m->phone_tmat = calloc(m->n_phone, sizeof(int32_t));
     ent = s.buf + p;
+    m->ci_filler = calloc((size_t)m->n_ciphone, 1);
+    for (i = 0; i < m->n_ciphone; ++i)
+        m->ci_filler[i] = ent[(size_t)i * 12 + 8];
     for (i = 0; i < m->n_phone; ++i) {
         uint32_t a, b;
         memcpy(&a, ent + (size_t)i * 12, 4);
@@ -968,6 +996,9 @@ orc_model_free(orc_model_t *m)
     free(m->sen2cimap);
     free(m->phone_ssid);
     free(m->phone_tmat);
+    free(m->cd_tree);
+    free(m->ci_filler);
+    free(m->ciname);
     free(m->tp);
     free(m->ptm_mixw);
     free(m->mixw_cb);
@@ -1922,4 +1953,87 @@ done:
     free(hmms);
     free(tokens);
     return rv;
+}
+
+/* ================================================================================== */
+/* triphone lookup: src/bin_mdef.c:543-720 (only used to build the inputs of the       */
+/* end-to-end alignment pin; alignment_populate itself is restated in tests/)         */
+/* ================================================================================== */
+
+/* bin_mdef_ciphone_id: linear scan is enough here (the reference bisects a sorted list) */
+int
+orc_mdef_ciphone_id(const orc_model_t *m, const char *name)
+{
+    size_t p = 0;
+    int i;
+    for (i = 0; i < m->n_ciphone && p < m->ciname_len; ++i) {
+        if (strcmp(m->ciname + p, name) == 0)
+            return i;
+        p += strlen(m->ciname + p) + 1;
+    }
+    return -1;
+}
+
+/* bin_mdef_phone_id, src/bin_mdef.c:596-664: walk wpos -> base -> left -> right */
+static int
+mdef_phone_id(const orc_model_t *m, int ci, int lc, int rc, int wpos)
+{
+    int ctx[4], level = 0, max = 4 /* N_WORD_POSN */, i;
+    size_t node = 0;
+    if (lc < 0 && rc < 0 && wpos == 4)
+        return ci;
+    if (m->cd_tree == NULL || lc < 0 || rc < 0 || wpos == 4)
+        return -1;
+    ctx[0] = wpos;
+    ctx[1] = ci;
+    ctx[2] = (m->sil >= 0 && m->ci_filler[lc]) ? m->sil : lc;
+    ctx[3] = (m->sil >= 0 && m->ci_filler[rc]) ? m->sil : rc;
+    while (level < 4) {
+        int16_t c, n_down;
+        int32_t down;
+        for (i = 0; i < max; ++i) {
+            memcpy(&c, m->cd_tree + (node + (size_t)i) * 8, 2);
+            if (c == ctx[level])
+                break;
+        }
+        if (i == max)
+            return -1;
+        memcpy(&n_down, m->cd_tree + (node + (size_t)i) * 8 + 2, 2);
+        memcpy(&down, m->cd_tree + (node + (size_t)i) * 8 + 4, 4);
+        if (n_down == 0)
+            return down; /* leaf: c.pid */
+        max = n_down;
+        node = (size_t)down;
+        ++level;
+    }
+    return -1;
+}
+
+/* bin_mdef_phone_id_nearest, src/bin_mdef.c:666-720 */
+int
+orc_mdef_phone_id_nearest(const orc_model_t *m, int b, int l, int r, int pos)
+{
+    int p, tmppos;
+    if (l < 0 || r < 0)
+        return b;
+    if ((p = mdef_phone_id(m, b, l, r, pos)) >= 0)
+        return p;
+    for (tmppos = 0; tmppos < 4; ++tmppos)
+        if (tmppos != pos && (p = mdef_phone_id(m, b, l, r, tmppos)) >= 0)
+            return p;
+    if (m->sil >= 0) {
+        int newl = l, newr = r;
+        if (m->ci_filler[l] || pos == 1 /* BEGIN */ || pos == 3 /* SINGLE */)
+            newl = m->sil;
+        if (m->ci_filler[r] || pos == 2 /* END */ || pos == 3)
+            newr = m->sil;
+        if (newl != l || newr != r) {
+            if ((p = mdef_phone_id(m, b, newl, newr, pos)) >= 0)
+                return p;
+            for (tmppos = 0; tmppos < 4; ++tmppos)
+                if (tmppos != pos && (p = mdef_phone_id(m, b, newl, newr, tmppos)) >= 0)
+                    return p;
+        }
+    }
+    return b;
 }

@@ -8,12 +8,14 @@
  * Every function restates one reference function in plain scalar C; the reference location
  * is cited as file:line relative to /root/reference.  No reference source is copied.
  *
- * PARITY PIN STATUS: the reference cannot be built here under the round's rules (every
- * translation unit needs the cmake-generated config.h; see DESIGN.md "Oracle").  The oracle is
- * pinned against (a) the reference's own known-answer test tests/test_log_shifted.c, (b) the
- * reference outputs recorded in SURVEY.md Appendix C (log-add tables, model counts, floored
- * variance count, tmat row 0) and (c) tests/data + model files the reference ships.  The
- * end-to-end Appendix C alignment pin needs the acoustic front end and is tracked in DESIGN.md.
+ * PARITY PIN STATUS: pinned.  The reference cannot be built here under the round's rules (its
+ * translation units need the cmake-generated config.h), so the oracle is
+ * pinned against outputs of the real library instead: (a) the reference's known-answer test
+ * tests/test_log_shifted.c, (b) its golden front-end table tests/_test_fe.res, (c) the values
+ * SURVEY.md Appendix C records from the library (log-add tables, model counts, tmat row 0) and
+ * (d) end to end: the reference's printed phone alignment of tests/data/goforward.wav -- 18
+ * exact (start, duration, score) triples and 6 word scores -- which this oracle reproduces from
+ * the PCM samples (tests/test_oracle_e2e_goforward.py).
  */
 #ifndef SSW_ORACLE_H
 #define SSW_ORACLE_H
@@ -139,6 +141,11 @@ int orc_state_align(const orc_model_t *m, const uint8_t *tp_override, const int1
 int32_t orc_hmm_vit_eval(int n_emit, const uint8_t *tp /* [n_emit][n_emit+1] */,
                          const int16_t *senscr, const uint16_t *senid, int32_t *score,
                          int32_t *history, int32_t *out);
+
+/* ---- triphone lookup (src/bin_mdef.c:543-720); word positions: 0 internal, 1 begin, 2 end,
+ * 3 single ------------------------------------------------------------------------------- */
+int orc_mdef_ciphone_id(const orc_model_t *m, const char *name);
+int orc_mdef_phone_id_nearest(const orc_model_t *m, int b, int l, int r, int pos);
 
 /* ---- front end + dynamic features (oracle/ssw_oracle_fe.c): only to reproduce the
  * reference's recorded alignment of tests/data/goforward.wav end to end ---------------------- */

@@ -132,3 +132,46 @@ def test_renormalisation_path(gpu_en, orc_en):
     assert (status[0] == 0) == (rv == 0)
     if rv == 0:
         assert np.array_equal(st, rst)
+
+
+def test_goforward_end_to_end_matches_reference_output_on_gpu(gpu_en, orc_en, oracle_mod):
+    """Config 1 through the GPU: features of goforward (oracle front end) -> the mgau vtable
+    object scoring both passes frame by frame with the history carried across the rewind, as
+    decoder_alignment does -> ssw_align_batch with the word windows of the first pass.  Must
+    reproduce the reference library's recorded phone alignment exactly."""
+    from tests.test_oracle_e2e_goforward import (REF_WORDS, _parse_ref, goforward_alignment_inputs,
+                                                 goforward_features)
+    feats = goforward_features(oracle_mod)
+    g = ssw.PtmMgau(gpu_en)
+    n = len(feats)
+    for t in range(n):                       # first pass
+        g.frame_eval(feats[t], t)
+        g.frame_idx = t + 1
+    g.frame_idx = 0                          # acmod_rewind
+    scr = np.zeros((n, gpu_en.n_sen), np.int16)
+    for t in range(n):                       # second pass
+        scr[t] = g.frame_eval(feats[t], t)
+        g.frame_idx = t + 1
+    g.free()
+    phones, senid, tmat, sf, ef, state_init = goforward_alignment_inputs(oracle_mod, orc_en)
+    d = gpu_en.to_device(scr)
+    try:
+        st, status = gpu_en.align_batch(d, [0, n], [0, len(phones)], senid, tmat, sf, ef,
+                                        state_init)
+    finally:
+        gpu_en.device_free(d)
+    assert status[0] == 0
+    ph = gpu_en.propagate(st, np.arange(len(st)) // 3, len(phones))
+    got = [(phones[i][0], int(ph[i, 0]), int(ph[i, 1]), int(ph[i, 2])) for i in range(len(ph))]
+    assert got == _parse_ref()
+    words = gpu_en.propagate(ph, [p[3] for p in phones], len(REF_WORDS))
+    assert [tuple(int(x) for x in w) for w in words] == [(s, dd, sc) for (_, s, dd, sc) in REF_WORDS]
+    # the batched path (history reset at the utterance start) gives the same alignment here
+    scr2 = gpu_en.score_batch(feats)
+    d = gpu_en.to_device(scr2)
+    try:
+        st2, status2 = gpu_en.align_batch(d, [0, n], [0, len(phones)], senid, tmat, sf, ef,
+                                          state_init)
+    finally:
+        gpu_en.device_free(d)
+    assert status2[0] == 0 and np.array_equal(st2[:, :2], st[:, :2])

@@ -1,0 +1,151 @@
+"""End-to-end pin of the oracle against the reference's own output.
+
+SURVEY.md Appendix C records what the real SoundSwallower library printed for config 1:
+tests/data/goforward.wav, text "go forward ten meters", en-us, compallsen=yes -- the phone-level
+alignment `start+duration(score)` of all 18 phones and the word scores.  This test recomputes
+them with nothing but the oracle: front end -> batch CMN + 1s_c_d_dd -> PTM scoring (first pass
+over all frames, then the second pass after acmod_rewind WITHOUT a history reset, as
+decoder_alignment does, src/decoder.c:786-793) -> alignment_populate (restated below from
+src/ps_alignment.c:132-247 on top of the oracle's bin_mdef_phone_id_nearest) ->
+state_align_search.  Every score is an exact int; any deviation in the density arithmetic, the
+top-N state machine, the log-add chain, the Viterbi step or the backtrace shows up here.
+
+tests/golden/goforward.raw is the reference's tests/data/goforward.raw (the same samples as
+goforward.wav without its 44-byte header).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import MODEL_ROOT, ROOT
+
+# SURVEY.md Appendix C, compallsen=yes
+REF_PHONES = ("SIL 0+46(-90) G 46+8(-183) OW 54+10(-202) F 64+14(-286) AO 78+6(-204) "
+              "R 84+10(-161) W 94+7(-124) ER 101+11(-206) D 112+5(-81) T 117+15(-588) "
+              "EH 132+9(-150) N 141+12(-439) M 153+6(-72) IY 159+12(-580) T 171+3(-250) "
+              "ER 174+16(-281) Z 190+21(-626) SIL 211+67(-900)")
+REF_WORDS = [("<sil>", 0, 46, -90), ("go", 46, 18, -385), ("forward", 64, 53, -1062),
+             ("ten", 117, 36, -1177), ("meters", 153, 58, -1809), ("<sil>", 211, 67, -900)]
+
+
+def _parse_ref():
+    out = []
+    toks = REF_PHONES.split()
+    for name, rest in zip(toks[0::2], toks[1::2]):
+        se, sc = rest.split("(")
+        s, d = se.split("+")
+        out.append((name, int(s), int(d), int(sc.rstrip(")"))))
+    return out
+
+
+def _pronunciations(words):
+    d = os.path.join(MODEL_ROOT, "en-us")
+    want = set(words)
+    pron = {}
+    for fn in ("dict.txt", "noisedict.txt"):
+        with open(os.path.join(d, fn)) as fh:
+            for line in fh:
+                parts = line.split()
+                if parts and parts[0] in want and parts[0] not in pron:
+                    pron[parts[0]] = parts[1:]
+    return pron
+
+
+def populate(O, m, words):
+    """alignment_populate (src/ps_alignment.c:132-247): words [(name, start, dur)] -> per phone
+    (ciname, ssid, tmat, word index)."""
+    pron = _pronunciations([w[0] for w in words])
+    ci = lambda n: O.ciphone_id(m, n)
+    sil = ci("SIL")
+    ssid_of, tmat_of = m.phone_ssid, m.phone_tmat
+    phones = []
+    lc = sil
+    for i, (w, _, _) in enumerate(words):
+        p = [ci(x) for x in pron[w]]
+        assert min(p) >= 0
+        rc = ci(pron[words[i + 1][0]][0]) if i < len(words) - 1 else sil
+        n = len(p)
+        if n == 1:   # dict2pid_lrdiph_rc
+            pid = O.phone_id_nearest(m, p[0], lc, rc, 3)
+            phones.append((pron[w][0], int(ssid_of[pid]), int(tmat_of[p[0]]), i))
+        else:        # dict2pid_ldiph_lc
+            pid = O.phone_id_nearest(m, p[0], lc, p[1], 1)
+            phones.append((pron[w][0], int(ssid_of[pid]), int(tmat_of[p[0]]), i))
+            for j in range(1, n - 1):   # dict2pid_internal
+                pid = O.phone_id_nearest(m, p[j], p[j - 1], p[j + 1], 0)
+                phones.append((pron[w][j], int(ssid_of[pid]), int(tmat_of[p[j]]), i))
+            pid = O.phone_id_nearest(m, p[-1], p[-2], rc, 2)   # rssid[...][cimap[rc]]
+            phones.append((pron[w][-1], int(ssid_of[pid]), int(tmat_of[p[-1]]), i))
+        lc = p[-1]
+    return phones
+
+
+def goforward_features(O):
+    pcm = np.fromfile(os.path.join(ROOT, "tests", "golden", "goforward.raw"), dtype="<i2")
+    assert len(pcm) == 44580
+    # model/en-us/feat_params.json
+    cep = O.fe_mfcc(pcm, nfilt=20, lowerf=130, upperf=3700, lifter=22, remove_noise=True,
+                    transform="dct")
+    assert cep.shape == (278, 13)            # decoder_n_frames = 279 = output_frame + 1
+    return O.feat_1s_c_d_dd(cep)
+
+
+def two_pass_scores(m, feats):
+    """First pass scores every frame once; decoder_alignment then rewinds (frame_idx = 0) and
+    scores every frame again, carrying the top-N history over (no reset)."""
+    m.ptm_score_utt(feats)
+    m.ptm_set_frame_idx(0)
+    out = np.zeros((len(feats), m.n_sen), np.int16)
+    for t in range(len(feats)):
+        out[t] = m.ptm_frame_eval(feats[t], t)
+        m.ptm_set_frame_idx(t + 1)
+    return out
+
+
+def goforward_alignment_inputs(O, m):
+    words = [(w, s, d) for (w, s, d, _) in REF_WORDS]
+    phones = populate(O, m, words)
+    ssid = np.array([p[1] for p in phones])
+    senid = m.sseq[ssid]
+    tmat = np.array([p[2] for p in phones], np.int16)
+    wstart = np.array([words[p[3]][1] for p in phones], np.int32)
+    wdur = np.array([words[p[3]][2] for p in phones], np.int32)
+    sf = np.where(wstart > 0, wstart, 0).astype(np.int32)      # state_align_search.c:464-467
+    ef = np.where(wdur > 0, wstart + wdur, 2**31 - 1).astype(np.int32)
+    state_init = np.stack([np.repeat(wstart, 3), np.repeat(wdur, 3),
+                           np.zeros(3 * len(phones), np.int32)], 1).astype(np.int32)
+    return phones, senid, tmat, sf, ef, state_init
+
+
+def test_front_end_matches_reference_golden_table(oracle_mod):
+    """tests/_test_fe.res lines 11-15: MFCCs of the first 1024 samples with the default front
+    end, printed with two decimals by tests/test_fe.c."""
+    pcm = np.fromfile(os.path.join(ROOT, "tests", "golden", "goforward.raw"), dtype="<i2")[:1024]
+    golden = """5.31 -0.58 -0.21 -0.00 -0.02 -0.08 -0.11 -0.05 0.09 0.01 -0.09 -0.20 -0.08
+5.19 -0.54 -0.16 -0.15 0.02 0.09 -0.06 -0.07 -0.08 -0.13 -0.24 -0.17 0.14
+5.19 -0.64 -0.20 -0.35 -0.03 -0.15 0.04 0.01 -0.14 -0.02 0.01 -0.05 0.02
+5.36 -0.47 -0.17 -0.21 -0.12 -0.12 -0.08 -0.04 -0.05 0.00 -0.02 0.01 -0.01
+5.21 -0.58 -0.15 -0.05 -0.16 -0.13 -0.17 -0.20 -0.16 -0.04 -0.00 0.03 -0.08"""
+    want = [ln.split() for ln in golden.splitlines()]
+    cep = oracle_mod.fe_mfcc(pcm)
+    assert cep.shape == (5, 13)
+    got = [["%.2f" % v for v in row] for row in cep]
+    assert got == want
+
+
+def test_goforward_alignment_matches_reference_output(oracle_mod, orc_en):
+    O, m = oracle_mod, orc_en
+    feats = goforward_features(O)
+    scr = two_pass_scores(m, feats)
+    phones, senid, tmat, sf, ef, state_init = goforward_alignment_inputs(O, m)
+    ref = _parse_ref()
+    assert [p[0] for p in phones] == [r[0] for r in ref]      # js/tests.js:127-130 phone string
+    rv, st, ph = m.state_align(scr, senid, tmat, sf=sf, ef=ef, state_init=state_init)
+    assert rv == 0
+    got = [(phones[i][0], int(ph[i, 0]), int(ph[i, 1]), int(ph[i, 2])) for i in range(len(ph))]
+    assert got == ref
+    parent = np.array([p[3] for p in phones])
+    words = [(int(ph[parent == w, 0][0]), int(ph[parent == w, 1].sum()), int(ph[parent == w, 2].sum()))
+             for w in range(len(REF_WORDS))]
+    assert words == [(s, d, sc) for (_, s, d, sc) in REF_WORDS]
