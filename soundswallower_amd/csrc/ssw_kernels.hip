@@ -760,58 +760,63 @@ fast_logadd(int x, int y, const uint8_t *tab)
     return r - (int)tab[d];
 }
 
-/* One workgroup per frame.  Senones are visited in "slot" order: grouped by codebook, each
- * group padded to a multiple of 4, so one lane owns 4 consecutive slots that share their top-N
- * block and fetches the 4 mixture weights of a (stream, codeword) row with one dword load.
- * R = quads per thread. */
-template <int TOPN, int R>
+/* One workgroup per FPB consecutive frames.  Senones are visited in "slot" order: grouped by
+ * codebook, each group padded to a multiple of 4, so one lane owns 4 consecutive slots that
+ * share their top-N block and fetches the 4 mixture weights of a (stream, codeword) row with one
+ * dword load.  R = quads per thread.  Several frames per workgroup amortise the prologue, the
+ * barriers and the launch of 704-thread groups, which is what bounded the one-frame version. */
+template <int TOPN, int R, int FPB, int NF>
 __global__ void __launch_bounds__(SEN_MAX_THREADS)
 ptm_senone_kernel(SenoneParams P)
 {
+    /* NF = number of streams when known at compile time (0 = read it from P): with a constant
+     * trip count the 12 row loads of a quad are all issued before the first log-add */
+    const int n_feat = NF ? NF : P.n_feat;
     static_assert(TOPN == 4, "top-N block is packed 4 x 8 bit");
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_cbf = P.n_cb * P.n_feat;
-    /* LDS carve: logadd[256] | norm[8] | ns4[n_cbf] | cw4[n_cbf] | red[16] */
+    /* LDS carve: logadd[256] | norm[FPB][8] | ns4[FPB][n_cbf] | cw4[FPB][n_cbf] | red[FPB][16] */
     uint8_t *s_tab = smem;
     int *s_norm = reinterpret_cast<int *>(smem + 256);
-    uint32_t *s_ns4 = reinterpret_cast<uint32_t *>(smem + 256 + 4 * SSW_MAX_FEAT);
-    uint32_t *s_cw4 = s_ns4 + n_cbf;
-    int *s_red = reinterpret_cast<int *>(s_cw4 + n_cbf);
+    uint32_t *s_ns4 = reinterpret_cast<uint32_t *>(smem + 256 + 4 * SSW_MAX_FEAT * FPB);
+    uint32_t *s_cw4 = s_ns4 + FPB * n_cbf;
+    int *s_red = reinterpret_cast<int *>(s_cw4 + FPB * n_cbf);
 
-    const int t = blockIdx.x;
+    const int t0 = blockIdx.x * FPB;
+    const int nfr = (P.n_frames - t0) < FPB ? (P.n_frames - t0) : FPB;
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
-    const uint32_t *cwrow = P.topn_cw + (size_t)t * n_cbf;
-    const int4 *scrow = P.topn_sc + (size_t)t * n_cbf;
 
     if (tid < 256)
         s_tab[tid] = P.logadd8[tid];
-    if (tid < SSW_MAX_FEAT)
+    if (tid < SSW_MAX_FEAT * FPB)
         s_norm[tid] = SSW_WORST_SCORE;
-    if (P.flags != nullptr) { /* this frame's flag bits have been consumed by the fix-up pass */
-        long long b0 = (long long)t * n_cbf, b1 = b0 + n_cbf - 1;
+    if (P.flags != nullptr) { /* these frames' flag bits have been consumed by the fix-up pass */
+        long long b0 = (long long)t0 * n_cbf, b1 = b0 + (long long)nfr * n_cbf - 1;
         int w0 = (int)(b0 >> 5), w1 = (int)(b1 >> 5);
-        if (tid <= w1 - w0)
-            P.flags[w0 + tid] = 0u;
-        if (t == 0 && tid == 0) {
+        for (int w = w0 + tid; w <= w1; w += nthr)
+            P.flags[w] = 0u;
+        if (blockIdx.x == 0 && tid == 0) {
             P.nfixed[1] = P.nfixed[0];
             P.nfixed[0] = 0ull;
         }
     }
     __syncthreads();
     /* per-stream normaliser: max over codebooks of (best >> 10), src/ptm_mgau.c:271-278;
-     * one thread per (codebook, stream), combined with LDS atomics */
+     * one thread per (frame, codebook, stream), combined with LDS atomics */
     int4 my_sc = make_int4(0, 0, 0, 0);
     uint32_t my_cw = 0;
-    if (tid < n_cbf) {
-        my_sc = scrow[tid];
-        my_cw = cwrow[tid];
-        atomicMax(&s_norm[tid % P.n_feat], my_sc.x >> SSW_SENSCR_SHIFT);
+    const int my_fr = tid / n_cbf, my_i = tid - my_fr * n_cbf;
+    const bool own = my_fr < nfr;
+    if (own) {
+        my_sc = P.topn_sc[(size_t)(t0 + my_fr) * n_cbf + my_i];
+        my_cw = P.topn_cw[(size_t)(t0 + my_fr) * n_cbf + my_i];
+        atomicMax(&s_norm[my_fr * SSW_MAX_FEAT + my_i % n_feat], my_sc.x >> SSW_SENSCR_SHIFT);
     }
     __syncthreads();
     /* s = min(96, -((s >> 10) - norm)), src/ptm_mgau.c:284-290 */
-    if (tid < n_cbf) {
-        int norm = s_norm[tid % P.n_feat];
+    if (own) {
+        int norm = s_norm[my_fr * SSW_MAX_FEAT + my_i % n_feat];
         int v[4] = { my_sc.x, my_sc.y, my_sc.z, my_sc.w };
         uint32_t pk = 0;
 #pragma unroll
@@ -820,74 +825,122 @@ ptm_senone_kernel(SenoneParams P)
             q = q > SSW_MAX_NEG_ASCR ? SSW_MAX_NEG_ASCR : q;
             pk |= (uint32_t)(q & 0xff) << (8 * k);
         }
-        s_ns4[tid] = pk;
-        s_cw4[tid] = my_cw;
+        s_ns4[my_fr * n_cbf + my_i] = pk;
+        s_cw4[my_fr * n_cbf + my_i] = my_cw;
     }
     __syncthreads();
 
     /* senone combine, src/ptm_mgau.c:342-395 */
-    int asc[R][4];
-    int best = INT_MAX;
+    int asc[R][FPB][4];
+    int best[FPB];
+#pragma unroll
+    for (int fr = 0; fr < FPB; ++fr)
+        best[fr] = INT_MAX;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int q = r * nthr + tid;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            asc[r][j] = 0;
+        for (int fr = 0; fr < FPB; ++fr)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                asc[r][fr][j] = 0;
         if (q < P.n_quads) {
             const int cb = P.quad_cb[q];
             const uint8_t *mq = P.mixw + (size_t)q * 4;
-            for (int f = 0; f < P.n_feat; ++f) {
-                const uint32_t cw4 = s_cw4[cb * P.n_feat + f];
-                const uint32_t ns4 = s_ns4[cb * P.n_feat + f];
-                uint32_t mw[TOPN];
-#pragma unroll
-                for (int k = 0; k < TOPN; ++k) {
-                    const uint32_t cw = (cw4 >> (8 * k)) & 0xffu;
-                    mw[k] = *reinterpret_cast<const uint32_t *>(
-                        mq + ((size_t)f * P.n_density + cw) * P.slot_stride);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int fden = (int)((mw[0] >> (8 * j)) & 0xffu) + (int)(ns4 & 0xffu);
-#pragma unroll
-                    for (int k = 1; k < TOPN; ++k) {
-                        int y = (int)((mw[k] >> (8 * j)) & 0xffu) + (int)((ns4 >> (8 * k)) & 0xffu);
-                        fden = fast_logadd(fden, y, s_tab);
-                    }
-                    asc[r][j] += fden;
-                }
-            }
             const short4 sen = P.slot_sen[q];
             const int sj[4] = { sen.x, sen.y, sen.z, sen.w };
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (sj[j] >= 0)
-                    best = asc[r][j] < best ? asc[r][j] : best;
+            for (int fr = 0; fr < FPB; ++fr) {
+                if (fr < nfr) {
+                    if (NF) {
+                        uint32_t mw[NF ? NF : 1][TOPN], ns4[NF ? NF : 1];
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) {
+                            const uint32_t cw4 = s_cw4[fr * n_cbf + cb * NF + f];
+                            ns4[f] = s_ns4[fr * n_cbf + cb * NF + f];
+#pragma unroll
+                            for (int k = 0; k < TOPN; ++k) {
+                                const uint32_t cw = (cw4 >> (8 * k)) & 0xffu;
+                                mw[f][k] = *reinterpret_cast<const uint32_t *>(
+                                    mq + ((uint32_t)f * P.n_density + cw) * (uint32_t)P.slot_stride);
+                            }
+                        }
+#pragma unroll
+                        for (int f = 0; f < NF; ++f)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                int fden = (int)((mw[f][0] >> (8 * j)) & 0xffu)
+                                    + (int)(ns4[f] & 0xffu);
+#pragma unroll
+                                for (int k = 1; k < TOPN; ++k) {
+                                    int y = (int)((mw[f][k] >> (8 * j)) & 0xffu)
+                                        + (int)((ns4[f] >> (8 * k)) & 0xffu);
+                                    fden = fast_logadd(fden, y, s_tab);
+                                }
+                                asc[r][fr][j] += fden;
+                            }
+                    } else
+                    for (int f = 0; f < n_feat; ++f) {
+                        const uint32_t cw4 = s_cw4[fr * n_cbf + cb * n_feat + f];
+                        const uint32_t ns4 = s_ns4[fr * n_cbf + cb * n_feat + f];
+                        uint32_t mw[TOPN];
+#pragma unroll
+                        for (int k = 0; k < TOPN; ++k) {
+                            const uint32_t cw = (cw4 >> (8 * k)) & 0xffu;
+                            mw[k] = *reinterpret_cast<const uint32_t *>(
+                                mq + ((size_t)f * P.n_density + cw) * P.slot_stride);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            int fden = (int)((mw[0] >> (8 * j)) & 0xffu) + (int)(ns4 & 0xffu);
+#pragma unroll
+                            for (int k = 1; k < TOPN; ++k) {
+                                int y = (int)((mw[k] >> (8 * j)) & 0xffu)
+                                    + (int)((ns4 >> (8 * k)) & 0xffu);
+                                fden = fast_logadd(fden, y, s_tab);
+                            }
+                            asc[r][fr][j] += fden;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (sj[j] >= 0)
+                            best[fr] = asc[r][fr][j] < best[fr] ? asc[r][fr][j] : best[fr];
+                }
+            }
         }
     }
-    /* block minimum */
+    /* block minimum of every frame */
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        int o = __shfl_xor(best, off, WAVE);
-        best = o < best ? o : best;
+    for (int fr = 0; fr < FPB; ++fr) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            int o = __shfl_xor(best[fr], off, WAVE);
+            best[fr] = o < best[fr] ? o : best[fr];
+        }
+        if ((tid & 63) == 0)
+            s_red[fr * 16 + (tid >> 6)] = best[fr];
     }
-    if ((tid & 63) == 0)
-        s_red[tid >> 6] = best;
     __syncthreads();
     if (tid < 64) {
-        int b = tid < (nthr >> 6) ? s_red[tid] : INT_MAX;
 #pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) {
-            int o = __shfl_xor(b, off, WAVE);
-            b = o < b ? o : b;
+        for (int fr = 0; fr < FPB; ++fr) {
+            int b = tid < (nthr >> 6) ? s_red[fr * 16 + tid] : INT_MAX;
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+                int o = __shfl_xor(b, off, WAVE);
+                b = o < b ? o : b;
+            }
+            best[fr] = b;
         }
-        if (tid == 0)
-            s_red[0] = b;
     }
     __syncthreads();
-    best = s_red[0];
-    int16_t *orow = P.out + (size_t)t * P.n_sen;
+    if (tid == 0) {
+#pragma unroll
+        for (int fr = 0; fr < FPB; ++fr)
+            s_red[fr * 16] = best[fr];
+    }
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int q = r * nthr + tid;
@@ -895,9 +948,16 @@ ptm_senone_kernel(SenoneParams P)
             const short4 sen = P.slot_sen[q];
             const int sj[4] = { sen.x, sen.y, sen.z, sen.w };
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (sj[j] >= 0) /* int16 arithmetic as in src/ptm_mgau.c:394-400 */
-                    orow[sj[j]] = (int16_t)((int16_t)asc[r][j] - (int16_t)best);
+            for (int fr = 0; fr < FPB; ++fr) {
+                if (fr < nfr) {
+                    const int b = s_red[fr * 16];
+                    int16_t *orow = P.out + (size_t)(t0 + fr) * P.n_sen;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (sj[j] >= 0) /* int16 arithmetic as in src/ptm_mgau.c:394-400 */
+                            orow[sj[j]] = (int16_t)((int16_t)asc[r][fr][j] - (int16_t)b);
+                }
+            }
         }
     }
 }
@@ -1719,13 +1779,16 @@ launch_senone(ssw_model_s *m, int scorer, int n_frames, const uint32_t *cw, cons
     S.n_sen = h->n_sen;
     S.slot_stride = m->slot_stride;
     S.n_quads = m->n_quads;
-    size_t lds = 256 + 4 * SSW_MAX_FEAT + 8 * (size_t)m->n_cbf + 16 * sizeof(int);
+    /* frames per workgroup: 4 when the batch still leaves >= 2 workgroups per CU, and the
+     * prologue can give every (frame, codebook, stream) its own thread */
+    int fpb = (n_frames >= 4 * 512 && 4 * m->n_cbf <= 704) ? 4 : 1;
+    size_t lds = 256 + (4 * SSW_MAX_FEAT + 8 * (size_t)m->n_cbf + 16 * sizeof(int)) * fpb;
     const int R = (m->n_quads + SEN_MAX_THREADS - 1) / SEN_MAX_THREADS;
     int threads = ((m->n_quads + R - 1) / R + 63) & ~63;
     if (threads < 256)
         threads = 256; /* the prologue copies the 256-entry table with the first 256 threads */
-    if (threads < ((m->n_cbf + 63) & ~63))
-        threads = (m->n_cbf + 63) & ~63; /* ... and owns one (codebook, stream) per thread */
+    if (threads < ((fpb * m->n_cbf + 63) & ~63))
+        threads = (fpb * m->n_cbf + 63) & ~63; /* ... and owns one (frame, cb, stream) per thread */
     if (threads > SEN_MAX_THREADS) {
         ssw_set_error("too many codebook x stream pairs (%d)", m->n_cbf);
         return -1;
@@ -1744,11 +1807,21 @@ launch_senone(ssw_model_s *m, int scorer, int n_frames, const uint32_t *cw, cons
         HIP_OK(hipGetLastError());
         return 0;
     }
+    const dim3 grid((n_frames + fpb - 1) / fpb);
+#define SSW_SEN_LAUNCH(RR)                                                                   \
+    if (fpb == 4 && h->n_feat == 3)                                                          \
+        hipLaunchKernelGGL((ptm_senone_kernel<4, RR, 4, 3>), grid, dim3(threads), lds, st, S); \
+    else if (fpb == 4)                                                                       \
+        hipLaunchKernelGGL((ptm_senone_kernel<4, RR, 4, 0>), grid, dim3(threads), lds, st, S); \
+    else if (h->n_feat == 3)                                                                 \
+        hipLaunchKernelGGL((ptm_senone_kernel<4, RR, 1, 3>), grid, dim3(threads), lds, st, S); \
+    else                                                                                     \
+        hipLaunchKernelGGL((ptm_senone_kernel<4, RR, 1, 0>), grid, dim3(threads), lds, st, S)
     switch (R) {
-    case 1: hipLaunchKernelGGL((ptm_senone_kernel<4, 1>), dim3(n_frames), dim3(threads), lds, st, S); break;
-    case 2: hipLaunchKernelGGL((ptm_senone_kernel<4, 2>), dim3(n_frames), dim3(threads), lds, st, S); break;
-    case 3: hipLaunchKernelGGL((ptm_senone_kernel<4, 3>), dim3(n_frames), dim3(threads), lds, st, S); break;
-    case 4: hipLaunchKernelGGL((ptm_senone_kernel<4, 4>), dim3(n_frames), dim3(threads), lds, st, S); break;
+    case 1: SSW_SEN_LAUNCH(1); break;
+    case 2: SSW_SEN_LAUNCH(2); break;
+    case 3: SSW_SEN_LAUNCH(3); break;
+    case 4: SSW_SEN_LAUNCH(4); break;
     default:
         ssw_set_error("too many senones (%d quads)", m->n_quads);
         return -1;
