@@ -781,6 +781,9 @@ ptm_senone_kernel(SenoneParams P)
     uint32_t *s_ns4 = reinterpret_cast<uint32_t *>(smem + 256 + 4 * SSW_MAX_FEAT * FPB);
     uint32_t *s_cw4 = s_ns4 + FPB * n_cbf;
     int *s_red = reinterpret_cast<int *>(s_cw4 + FPB * n_cbf);
+    /* byte offsets of the 4 mixture-weight rows of every (frame, codebook, stream) */
+    uint4 *s_roff = reinterpret_cast<uint4 *>(
+        smem + ((reinterpret_cast<unsigned char *>(s_red + FPB * 16) - smem + 15) & ~(size_t)15));
 
     const int t0 = blockIdx.x * FPB;
     const int nfr = (P.n_frames - t0) < FPB ? (P.n_frames - t0) : FPB;
@@ -804,20 +807,20 @@ ptm_senone_kernel(SenoneParams P)
     __syncthreads();
     /* per-stream normaliser: max over codebooks of (best >> 10), src/ptm_mgau.c:271-278;
      * one thread per (frame, codebook, stream), combined with LDS atomics */
-    int4 my_sc = make_int4(0, 0, 0, 0);
-    uint32_t my_cw = 0;
-    const int my_fr = tid / n_cbf, my_i = tid - my_fr * n_cbf;
-    const bool own = my_fr < nfr;
-    if (own) {
-        my_sc = P.topn_sc[(size_t)(t0 + my_fr) * n_cbf + my_i];
-        my_cw = P.topn_cw[(size_t)(t0 + my_fr) * n_cbf + my_i];
-        atomicMax(&s_norm[my_fr * SSW_MAX_FEAT + my_i % n_feat], my_sc.x >> SSW_SENSCR_SHIFT);
+    const int n_items = nfr * n_cbf;
+    for (int it = tid; it < n_items; it += nthr) {
+        const int fr = it / n_cbf, i = it - fr * n_cbf;
+        const int top = P.topn_sc[(size_t)(t0 + fr) * n_cbf + i].x;
+        atomicMax(&s_norm[fr * SSW_MAX_FEAT + i % n_feat], top >> SSW_SENSCR_SHIFT);
     }
     __syncthreads();
     /* s = min(96, -((s >> 10) - norm)), src/ptm_mgau.c:284-290 */
-    if (own) {
-        int norm = s_norm[my_fr * SSW_MAX_FEAT + my_i % n_feat];
-        int v[4] = { my_sc.x, my_sc.y, my_sc.z, my_sc.w };
+    for (int it = tid; it < n_items; it += nthr) {
+        const int fr = it / n_cbf, i = it - fr * n_cbf;
+        const int4 sc = P.topn_sc[(size_t)(t0 + fr) * n_cbf + i];
+        const uint32_t cw = P.topn_cw[(size_t)(t0 + fr) * n_cbf + i];
+        const int norm = s_norm[fr * SSW_MAX_FEAT + i % n_feat];
+        const int v[4] = { sc.x, sc.y, sc.z, sc.w };
         uint32_t pk = 0;
 #pragma unroll
         for (int k = 0; k < TOPN; ++k) {
@@ -825,8 +828,13 @@ ptm_senone_kernel(SenoneParams P)
             q = q > SSW_MAX_NEG_ASCR ? SSW_MAX_NEG_ASCR : q;
             pk |= (uint32_t)(q & 0xff) << (8 * k);
         }
-        s_ns4[my_fr * n_cbf + my_i] = pk;
-        s_cw4[my_fr * n_cbf + my_i] = my_cw;
+        s_ns4[it] = pk;
+        s_cw4[it] = cw;
+        const uint32_t row0 = (uint32_t)(i % n_feat) * (uint32_t)P.n_density;
+        s_roff[it] = make_uint4(__umul24(row0 + (cw & 0xffu), (uint32_t)P.slot_stride),
+                                __umul24(row0 + ((cw >> 8) & 0xffu), (uint32_t)P.slot_stride),
+                                __umul24(row0 + ((cw >> 16) & 0xffu), (uint32_t)P.slot_stride),
+                                __umul24(row0 + (cw >> 24), (uint32_t)P.slot_stride));
     }
     __syncthreads();
 
@@ -856,14 +864,13 @@ ptm_senone_kernel(SenoneParams P)
                         uint32_t mw[NF ? NF : 1][TOPN], ns4[NF ? NF : 1];
 #pragma unroll
                         for (int f = 0; f < NF; ++f) {
-                            const uint32_t cw4 = s_cw4[fr * n_cbf + cb * NF + f];
+                            const uint4 ro = s_roff[fr * n_cbf + cb * NF + f];
+                            const uint32_t q4 = (uint32_t)q * 4u;
                             ns4[f] = s_ns4[fr * n_cbf + cb * NF + f];
-#pragma unroll
-                            for (int k = 0; k < TOPN; ++k) {
-                                const uint32_t cw = (cw4 >> (8 * k)) & 0xffu;
-                                mw[f][k] = *reinterpret_cast<const uint32_t *>(
-                                    mq + ((uint32_t)f * P.n_density + cw) * (uint32_t)P.slot_stride);
-                            }
+                            mw[f][0] = *reinterpret_cast<const uint32_t *>(P.mixw + (ro.x + q4));
+                            mw[f][1] = *reinterpret_cast<const uint32_t *>(P.mixw + (ro.y + q4));
+                            mw[f][2] = *reinterpret_cast<const uint32_t *>(P.mixw + (ro.z + q4));
+                            mw[f][3] = *reinterpret_cast<const uint32_t *>(P.mixw + (ro.w + q4));
                         }
 #pragma unroll
                         for (int f = 0; f < NF; ++f)
@@ -1781,16 +1788,23 @@ launch_senone(ssw_model_s *m, int scorer, int n_frames, const uint32_t *cw, cons
     S.n_quads = m->n_quads;
     /* frames per workgroup: 4 when the batch still leaves >= 2 workgroups per CU, and the
      * prologue can give every (frame, codebook, stream) its own thread */
-    int fpb = (n_frames >= 4 * 512 && 4 * m->n_cbf <= 704) ? 4 : 1;
-    size_t lds = 256 + (4 * SSW_MAX_FEAT + 8 * (size_t)m->n_cbf + 16 * sizeof(int)) * fpb;
-    const int R = (m->n_quads + SEN_MAX_THREADS - 1) / SEN_MAX_THREADS;
+    int fpb = n_frames >= 4 * 512 ? 4 : 1;
+    size_t lds = 256 + (4 * SSW_MAX_FEAT + 24 * (size_t)m->n_cbf + 16 * sizeof(int)) * fpb + 16;
+    /* quads per thread: as few as a 1024-thread workgroup allows (measured on MI355X, en-us:
+     * R = 2 -> 58 us, 3 -> 59 us, 4 -> 78 us per 4096 frames; more quads per thread only adds
+     * register pressure) */
+    int R = (m->n_quads + SEN_MAX_THREADS - 1) / SEN_MAX_THREADS;
+    {
+        const char *e = getenv("SSW_SEN_R");
+        if (e != NULL && e[0] >= '1' && e[0] <= '4')
+            R = e[0] - '0';
+    }
     int threads = ((m->n_quads + R - 1) / R + 63) & ~63;
     if (threads < 256)
         threads = 256; /* the prologue copies the 256-entry table with the first 256 threads */
-    if (threads < ((fpb * m->n_cbf + 63) & ~63))
-        threads = (fpb * m->n_cbf + 63) & ~63; /* ... and owns one (frame, cb, stream) per thread */
-    if (threads > SEN_MAX_THREADS) {
-        ssw_set_error("too many codebook x stream pairs (%d)", m->n_cbf);
+    if (threads > SEN_MAX_THREADS || (scorer == SSW_SCORER_MS && threads < m->n_cbf)) {
+        ssw_set_error("unsupported senone/codebook shape (%d quads, %d codebook x stream)",
+                      m->n_quads, m->n_cbf);
         return -1;
     }
     if (scorer == SSW_SCORER_MS) {
