@@ -104,6 +104,8 @@ struct ChainParams {
     const int *utt_off;   /* [n_utts+1] (chain mode) */
     const int *work;      /* fix-up mode: [n_work] packed (frame << 8 | cbf) run heads */
     const uint32_t *carry_pk; /* optional [n_utts][n_cb*n_feat] packed cw order to start from */
+    const uint8_t *cb_active; /* optional [n_cb]: 0 = only re-score the carried codewords
+                               * (ptm_mgau_codebook_eval skips eval_cb, src/ptm_mgau.c:245-251) */
     uint32_t *topn_cw;    /* [n_frames][n_cb*n_feat] 4 x uint8 packed */
     int4 *topn_sc;        /* [n_frames][n_cb*n_feat] raw scores */
     const uint32_t *flags;/* fix-up mode: bit per (frame, cbf) */
@@ -322,6 +324,8 @@ ptm_topn_chain_kernel(ChainParams P)
         Ls[k] = INT_MIN;
     for (int t = t0; t < t1; ++t) {
         bool do_scan = ((t - t0 + P.frame_base) % P.ds) == 0; /* src/ptm_mgau.c:241 */
+        if (P.cb_active != nullptr && P.cb_active[cbf / P.n_feat] == 0)
+            do_scan = false;
         chain_frame<VECLEN, NDL, TOPN>(P, t, cbf, f, do_scan, lane, mean, var, det, Lc, Ls);
     }
 }
@@ -747,6 +751,8 @@ struct SenoneParams {
     int16_t *out;            /* [n_frames][n_sen] */
     int n_frames, n_cb, n_feat, n_density, n_sen, slot_stride, n_quads;
     int aw, zero; /* ms scorer: acoustic weight divisor, logmath zero at shift 10 */
+    int raw;      /* ms scorer: 1 = skip the frame normalisation (the caller applies it over an
+                   * active set, src/ms_mgau.c:342-364) */
 };
 
 constexpr int SEN_MAX_THREADS = 1024;
@@ -969,6 +975,107 @@ ptm_senone_kernel(SenoneParams P)
     }
 }
 
+/* One frame with an explicit active set: the compallsen = no half of ptm_mgau_frame_eval
+ * (src/ptm_mgau.c:264-403).  cb_active is the activity the top-N block was computed with
+ * (the history slot's mgau_active): the per-stream normaliser runs over active codebooks only and
+ * senones of inactive codebooks see 96 for all their scores (:353-364).  sen_active marks the
+ * senones of the delta list (bridge entries included); the best score is taken over them, and,
+ * as in the reference, it is subtracted from ALL n_sen entries, the others starting from 0. */
+struct SenoneFrameParams {
+    const uint32_t *topn_cw;
+    const int4 *topn_sc;
+    const uint8_t *mixw, *quad_cb, *logadd8, *cb_active, *sen_active;
+    const short4 *slot_sen;
+    int16_t *out;
+    int n_cb, n_feat, n_density, n_sen, slot_stride, n_quads;
+};
+
+__global__ void __launch_bounds__(1024)
+ptm_senone_frame_kernel(SenoneFrameParams P)
+{
+    __shared__ uint8_t s_tab[256];
+    __shared__ int s_norm[SSW_MAX_FEAT];
+    __shared__ int s_red[16];
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n_cbf = P.n_cb * P.n_feat;
+    uint32_t *s_ns4 = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *s_cw4 = s_ns4 + n_cbf;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+
+    if (tid < 256)
+        s_tab[tid] = P.logadd8[tid];
+    if (tid < SSW_MAX_FEAT)
+        s_norm[tid] = SSW_WORST_SCORE;
+    __syncthreads();
+    for (int i = tid; i < n_cbf; i += nthr)
+        if (P.cb_active[i / P.n_feat])
+            atomicMax(&s_norm[i % P.n_feat], P.topn_sc[i].x >> SSW_SENSCR_SHIFT);
+    __syncthreads();
+    for (int i = tid; i < n_cbf; i += nthr) {
+        const int4 sc = P.topn_sc[i];
+        const int v[4] = { sc.x, sc.y, sc.z, sc.w };
+        const int norm = s_norm[i % P.n_feat];
+        uint32_t pk = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int q = -((v[k] >> SSW_SENSCR_SHIFT) - norm);
+            q = q > SSW_MAX_NEG_ASCR ? SSW_MAX_NEG_ASCR : q;
+            if (!P.cb_active[i / P.n_feat])
+                q = SSW_MAX_NEG_ASCR;
+            pk |= (uint32_t)(q & 0xff) << (8 * k);
+        }
+        s_ns4[i] = pk;
+        s_cw4[i] = P.topn_cw[i];
+    }
+    __syncthreads();
+    int best = INT_MAX;
+    for (int sl = tid; sl < P.n_quads * 4; sl += nthr) {
+        const short4 s4 = P.slot_sen[sl >> 2];
+        const int sj[4] = { s4.x, s4.y, s4.z, s4.w };
+        const int sen = sj[sl & 3];
+        if (sen < 0 || !P.sen_active[sen])
+            continue;
+        const int cb = P.quad_cb[sl >> 2];
+        int a = 0;
+        for (int f = 0; f < P.n_feat; ++f) {
+            const uint32_t cw4 = s_cw4[cb * P.n_feat + f], ns4 = s_ns4[cb * P.n_feat + f];
+            const uint8_t *mw = P.mixw + (size_t)f * P.n_density * P.slot_stride + sl;
+            int fden = (int)mw[(size_t)(cw4 & 0xffu) * P.slot_stride] + (int)(ns4 & 0xffu);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                int y = (int)mw[(size_t)((cw4 >> (8 * k)) & 0xffu) * P.slot_stride]
+                    + (int)((ns4 >> (8 * k)) & 0xffu);
+                fden = fast_logadd(fden, y, s_tab);
+            }
+            a += fden;
+        }
+        P.out[sen] = (int16_t)a; /* raw; normalised below */
+        best = a < best ? a : best;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        int o = __shfl_xor(best, off, WAVE);
+        best = o < best ? o : best;
+    }
+    if ((tid & 63) == 0)
+        s_red[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        int b = INT_MAX;
+        for (int w = 0; w < (nthr >> 6); ++w)
+            b = s_red[w] < b ? s_red[w] : b;
+        s_red[0] = b;
+    }
+    __syncthreads();
+    best = s_red[0];
+    __threadfence_block();
+    for (int sen = tid; sen < P.n_sen; sen += nthr) {
+        /* int16 -= int32 exactly as `senone_scores[i] -= bestscore` converts (src/ptm_mgau.c:399) */
+        int16_t cur = P.sen_active[sen] ? P.out[sen] : (int16_t)0;
+        P.out[sen] = (int16_t)((int)cur - best);
+    }
+}
+
 /* logmath_add on the shift-10 table (src/logmath.c:228-272): max(x, y) + table[|x - y|], with
  * the "zero" short-cuts; the table has exactly 256 entries for the bases the loader accepts. */
 __device__ __forceinline__ int
@@ -1084,7 +1191,7 @@ ms_senone_kernel(SenoneParams P)
             s_red[0] = b;
     }
     __syncthreads();
-    best = s_red[0];
+    best = P.raw ? 0 : s_red[0];
     int16_t *orow = P.out + (size_t)t * P.n_sen;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -1421,6 +1528,7 @@ struct ssw_model_s {
     size_t ws_frames, ws_utts;
     std::vector<int32_t> *utt_cache; /* last uploaded utterance offsets */
     int force_exact;            /* SSW_PTM_EXACT=1: always run the sequential chain kernel */
+    int ms_raw;                 /* next ms launch leaves its scores un-normalised */
     int stats_pending;
     int last_n_frames;
     int64_t stats[2];
@@ -1773,6 +1881,7 @@ launch_senone(ssw_model_s *m, int scorer, int n_frames, const uint32_t *cw, cons
     S.mixw = scorer == SSW_SCORER_MS ? m->d_ms_pdf : m->d_mixw;
     S.aw = h->cfg.aw;
     S.zero = h->zero8;
+    S.raw = m->ms_raw;
     S.quad_cb = m->d_quad_cb;
     S.slot_sen = m->d_slot_sen;
     S.logadd8 = m->d_logadd8;
@@ -2196,6 +2305,8 @@ struct ssw_mgau_impl {
     int *d_utt1;
     float *d_feat1;
     int16_t *d_out1;
+    uint8_t *d_cb_active[2]; /* mgau_active of each history slot */
+    uint8_t *d_sen_active;
     /* whole-utterance cache filled by ssw_mgau_prescore */
     std::vector<int16_t> cache;
     int cache_frames;
@@ -2213,8 +2324,12 @@ static int
 mgau_reset_device_hist(ssw_mgau_impl *g)
 {
     std::vector<uint32_t> init((size_t)g->m->n_cbf, 0x03020100u); /* cw = m */
-    for (int i = 0; i < 2; ++i)
+    std::vector<uint8_t> ones((size_t)g->m->h->n_cb, 1);         /* all codebooks active */
+    for (int i = 0; i < 2; ++i) {
         HIP_OK(hipMemcpy(g->d_hist_cw[i], init.data(), init.size() * 4, hipMemcpyHostToDevice));
+        if (g->d_cb_active[i] != NULL)
+            HIP_OK(hipMemcpy(g->d_cb_active[i], ones.data(), ones.size(), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -2239,13 +2354,24 @@ ssw_ptm_mgau_init(ssw_model_t *m)
     for (int i = 0; i < 2; ++i) {
         g->d_hist_cw[i] = NULL;
         g->d_hist_sc[i] = NULL;
+        g->d_cb_active[i] = NULL;
     }
+    g->d_sen_active = NULL;
     bool ok = true;
     for (int i = 0; i < 2 && ok; ++i)
         ok = dev_alloc(&g->d_hist_cw[i], (size_t)m->n_cbf) == 0
             && dev_alloc(&g->d_hist_sc[i], (size_t)m->n_cbf) == 0;
     ok = ok && dev_alloc(&g->d_utt1, 2) == 0 && dev_alloc(&g->d_feat1, (size_t)m->h->veclen_total) == 0
-        && dev_alloc(&g->d_out1, (size_t)m->h->n_sen) == 0;
+        && dev_alloc(&g->d_out1, (size_t)m->h->n_sen) == 0
+        && dev_alloc(&g->d_sen_active, (size_t)m->h->n_sen) == 0
+        && dev_alloc(&g->d_cb_active[0], (size_t)m->h->n_cb) == 0
+        && dev_alloc(&g->d_cb_active[1], (size_t)m->h->n_cb) == 0;
+    if (ok) { /* every codebook starts active (src/ptm_mgau.c:716-718) */
+        std::vector<uint8_t> ones((size_t)m->h->n_cb, 1);
+        for (int i = 0; i < 2 && ok; ++i)
+            ok = hipMemcpy(g->d_cb_active[i], ones.data(), ones.size(), hipMemcpyHostToDevice)
+                == hipSuccess;
+    }
     int one[2] = { 0, 1 };
     ok = ok && hipMemcpy(g->d_utt1, one, sizeof(one), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && mgau_reset_device_hist(g) == 0;
@@ -2280,7 +2406,9 @@ ssw_ms_mgau_init(ssw_model_t *m)
     for (int i = 0; i < 2; ++i) {
         g->d_hist_cw[i] = NULL;
         g->d_hist_sc[i] = NULL;
+        g->d_cb_active[i] = NULL;
     }
+    g->d_sen_active = NULL;
     if (dev_alloc(&g->d_feat1, (size_t)m->h->veclen_total) < 0
         || dev_alloc(&g->d_out1, (size_t)m->h->n_sen) < 0) {
         mgau_free(&g->base);
@@ -2314,8 +2442,31 @@ ssw_mgau_prescore(ssw_mgau_t *mg, const float *feats, int32_t n_frames)
     return 0;
 }
 
+/* uint8 delta list (acmod_flags2list, src/acmod.c:947-999) -> per-senone and per-codebook
+ * activity, exactly as ptm_mgau_calc_cb_active / ms_cont_mgau_frame_eval walk it */
+static int
+decode_active(const ssw_host_model_t *h, const uint8_t *list, int32_t n, std::vector<uint8_t> &sen,
+              std::vector<uint8_t> &cb)
+{
+    sen.assign((size_t)h->n_sen, 0);
+    cb.assign((size_t)h->n_cb, 0);
+    int last = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        int s = list[i] + last;
+        if (s >= h->n_sen) {
+            ssw_set_error("active list runs past the last senone (%d >= %d)", s, h->n_sen);
+            return -1;
+        }
+        sen[s] = 1;
+        cb[h->sen2cb[s]] = 1;
+        last = s;
+    }
+    return 0;
+}
+
 /* frame_eval slot of mgaufuncs_t (acmod.h:96-102); semantics of ptm_mgau_frame_eval
- * (src/ptm_mgau.c:408-454) for compallsen = yes. */
+ * (src/ptm_mgau.c:408-454) and ms_cont_mgau_frame_eval (src/ms_mgau.c:278-368), both for
+ * compallsen = yes and for an active-senone list. */
 static int
 mgau_frame_eval(ssw_mgau_t *mg, int16_t *senscr, uint8_t *senone_active,
                 int32_t n_senone_active, float **feat, int32_t frame, int32_t compallsen)
@@ -2323,43 +2474,69 @@ mgau_frame_eval(ssw_mgau_t *mg, int16_t *senscr, uint8_t *senone_active,
     ssw_mgau_impl *g = reinterpret_cast<ssw_mgau_impl *>(mg);
     ssw_model_s *m = g->m;
     const ssw_host_model_t *h = m->h;
-    (void)senone_active;
-    (void)n_senone_active;
-    if (!compallsen) {
-        ssw_set_error("frame_eval with compallsen=no is not built yet (SURVEY section 8(f) row 3)");
-        return -1;
-    }
     if (frame < 0) {
         ssw_set_error("negative frame");
         return -1;
     }
-    if (frame < g->cache_frames) {
+    if (!compallsen && (senone_active == NULL || n_senone_active < 0)) {
+        ssw_set_error("compallsen=no needs the active senone list");
+        return -1;
+    }
+    if (compallsen && frame < g->cache_frames) {
         memcpy(senscr, g->cache.data() + (size_t)frame * h->n_sen, sizeof(int16_t) * h->n_sen);
         return 0;
     }
     HIP_OK(hipSetDevice(m->device));
+    std::vector<uint8_t> sen_act, cb_act;
+    if (!compallsen && decode_active(h, senone_active, n_senone_active, sen_act, cb_act) < 0)
+        return -1;
+    float row[SSW_MAX_FEAT * SSW_MAX_VECLEN];
+    for (int f = 0; f < h->n_feat; ++f)
+        memcpy(row + h->featoff[f], feat[f], sizeof(float) * h->veclen[f]);
+
     if (g->scorer == SSW_SCORER_MS) { /* history-free: one frame is a batch of one */
-        float row[SSW_MAX_FEAT * SSW_MAX_VECLEN];
         int32_t off[2] = { 0, 1 };
-        for (int f = 0; f < h->n_feat; ++f)
-            memcpy(row + h->featoff[f], feat[f], sizeof(float) * h->veclen[f]);
         HIP_OK(hipMemcpy(g->d_feat1, row, sizeof(float) * h->veclen_total, hipMemcpyHostToDevice));
-        if (ssw_score_batch(m, SSW_SCORER_MS, g->d_feat1, 1, off, 1, g->d_out1, NULL) < 0)
+        m->ms_raw = compallsen ? 0 : 1;
+        int rv = ssw_score_batch(m, SSW_SCORER_MS, g->d_feat1, 1, off, 1, g->d_out1, NULL);
+        m->ms_raw = 0;
+        if (rv < 0)
             return -1;
-        HIP_OK(hipMemcpy(senscr, g->d_out1, sizeof(int16_t) * h->n_sen, hipMemcpyDeviceToHost));
+        if (compallsen) {
+            HIP_OK(hipMemcpy(senscr, g->d_out1, sizeof(int16_t) * h->n_sen, hipMemcpyDeviceToHost));
+            return 0;
+        }
+        /* only active senones are written; they are normalised by the best active one
+         * (src/ms_mgau.c:342-364).  Densities of inactive codebooks are simply not used. */
+        std::vector<int16_t> raw((size_t)h->n_sen);
+        HIP_OK(hipMemcpy(raw.data(), g->d_out1, sizeof(int16_t) * h->n_sen, hipMemcpyDeviceToHost));
+        int best = INT_MAX;
+        for (int s = 0; s < h->n_sen; ++s)
+            if (sen_act[s] && raw[s] < best)
+                best = raw[s];
+        for (int s = 0; s < h->n_sen; ++s)
+            if (sen_act[s]) {
+                int bs = raw[s] - best;
+                bs = bs > 32767 ? 32767 : bs;
+                bs = bs < -32768 ? -32768 : bs;
+                senscr[s] = (int16_t)bs;
+            }
         return 0;
     }
+
     const int slot = frame % 2;
     if (frame >= g->base.frame_idx) {
-        float row[SSW_MAX_FEAT * SSW_MAX_VECLEN];
-        for (int f = 0; f < h->n_feat; ++f)
-            memcpy(row + h->featoff[f], feat[f], sizeof(float) * h->veclen[f]);
         HIP_OK(hipMemcpy(g->d_feat1, row, sizeof(float) * h->veclen_total, hipMemcpyHostToDevice));
+        if (compallsen)
+            cb_act.assign((size_t)h->n_cb, 1);
+        HIP_OK(hipMemcpy(g->d_cb_active[slot], cb_act.data(), (size_t)h->n_cb,
+                         hipMemcpyHostToDevice));
         ChainParams P;
         fill_chain_params(m, P, g->d_feat1);
         P.utt_off = g->d_utt1;
         P.n_utts = 1;
         P.carry_pk = g->d_hist_cw[slot ^ 1]; /* lastf, src/ptm_mgau.c:435-441 */
+        P.cb_active = g->d_cb_active[slot];
         P.topn_cw = g->d_hist_cw[slot];
         P.topn_sc = g->d_hist_sc[slot];
         P.frame_base = frame;
@@ -2367,9 +2544,30 @@ mgau_frame_eval(ssw_mgau_t *mg, int16_t *senscr, uint8_t *senone_active,
                            dim3(256), 0, 0, P);
         HIP_OK(hipGetLastError());
     }
-    if (launch_senone(m, SSW_SCORER_PTM, 1, g->d_hist_cw[slot], g->d_hist_sc[slot], g->d_out1, NULL,
-                      0) < 0)
-        return -1;
+    if (compallsen)
+        sen_act.assign((size_t)h->n_sen, 1);
+    HIP_OK(hipMemcpy(g->d_sen_active, sen_act.data(), (size_t)h->n_sen, hipMemcpyHostToDevice));
+    {
+        SenoneFrameParams F;
+        F.topn_cw = g->d_hist_cw[slot];
+        F.topn_sc = g->d_hist_sc[slot];
+        F.mixw = m->d_mixw;
+        F.quad_cb = m->d_quad_cb;
+        F.logadd8 = m->d_logadd8;
+        F.cb_active = g->d_cb_active[slot];
+        F.sen_active = g->d_sen_active;
+        F.slot_sen = m->d_slot_sen;
+        F.out = g->d_out1;
+        F.n_cb = h->n_cb;
+        F.n_feat = h->n_feat;
+        F.n_density = h->n_density;
+        F.n_sen = h->n_sen;
+        F.slot_stride = m->slot_stride;
+        F.n_quads = m->n_quads;
+        hipLaunchKernelGGL(ptm_senone_frame_kernel, dim3(1), dim3(1024),
+                           8 * (size_t)m->n_cbf, 0, F);
+        HIP_OK(hipGetLastError());
+    }
     HIP_OK(hipMemcpy(senscr, g->d_out1, sizeof(int16_t) * h->n_sen, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -2392,7 +2590,9 @@ mgau_free(ssw_mgau_t *mg)
     for (int i = 0; i < 2; ++i) {
         (void)hipFree(g->d_hist_cw[i]);
         (void)hipFree(g->d_hist_sc[i]);
+        (void)hipFree(g->d_cb_active[i]);
     }
+    (void)hipFree(g->d_sen_active);
     (void)hipFree(g->d_utt1);
     (void)hipFree(g->d_feat1);
     (void)hipFree(g->d_out1);

@@ -31,8 +31,6 @@ def test_mgau_vtable_frame_by_frame_matches_reference_semantics(gpu_en, orc_en, 
                 assert np.array_equal(again, ref)
             g.frame_idx = t + 1               # acmod_advance
             orc_en.ptm_set_frame_idx(t + 1)
-    with pytest.raises(ssw.SswError, match="compallsen"):
-        g.frame_eval(feats[0], 0, compallsen=False, senone_active=np.zeros(1, np.uint8))
     g.free()
 
 
@@ -175,3 +173,40 @@ def test_goforward_end_to_end_matches_reference_output_on_gpu(gpu_en, orc_en, or
     finally:
         gpu_en.device_free(d)
     assert status2[0] == 0 and np.array_equal(st2[:, :2], st[:, :2])
+
+
+def _random_active_list(oracle_mod, n_sen, rng, density):
+    vec = np.zeros((n_sen + 31) // 32, np.uint32)
+    sens = np.flatnonzero(rng.random(n_sen) < density)
+    for s in sens:
+        vec[s // 32] |= np.uint32(1 << (s % 32))
+    return oracle_mod.flags2list(vec, n_sen)
+
+
+def test_mgau_vtable_compallsen_no(gpu_en, orc_en, oracle_mod, means_en):
+    """frame_eval with an active-senone delta list (src/ptm_mgau.c:297-321, 353-364, 392-400):
+    codebook activity follows the list, inactive codebooks only re-score their carried
+    codewords, the normaliser and the best score run over the active set, and the best score is
+    subtracted from every entry.  Sparse lists exercise the >255 bridge entries."""
+    rng = np.random.default_rng(5)
+    g = ssw.PtmMgau(gpu_en)
+    orc_en.ptm_reset()
+    feats = synth_features(means_en, 14, 321)
+    for t in range(len(feats)):
+        dens = (0.002, 0.02, 0.3, 1.0)[t % 4]
+        lst = _random_active_list(oracle_mod, orc_en.n_sen, rng, dens)
+        if t == 5:
+            lst = lst[:0]                                   # nothing active at all
+        got = g.frame_eval(feats[t], t, compallsen=False, senone_active=lst)
+        ref = orc_en.ptm_frame_eval(feats[t], t, compallsen=False, senone_active=lst)
+        assert np.array_equal(got, ref), t
+        if t == 8:      # mix in an all-senone frame, and re-score a past frame with a new list
+            g.frame_idx = t + 1
+            orc_en.ptm_set_frame_idx(t + 1)
+            lst2 = _random_active_list(oracle_mod, orc_en.n_sen, rng, 0.1)
+            again = g.frame_eval(feats[t], t, compallsen=False, senone_active=lst2)
+            ref2 = orc_en.ptm_frame_eval(feats[t], t, compallsen=False, senone_active=lst2)
+            assert np.array_equal(again, ref2)
+        g.frame_idx = t + 1
+        orc_en.ptm_set_frame_idx(t + 1)
+    g.free()

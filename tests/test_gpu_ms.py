@@ -74,3 +74,19 @@ def test_ptm_model_without_mixw_refuses_ms(gpu_en):
         gpu_en.score_batch(np.zeros((2, 39), np.float32), scorer=ssw.SCORER_MS)
     with pytest.raises(ssw.SswError):
         ssw.MsMgau(gpu_en)
+
+
+def test_ms_mgau_vtable_compallsen_no(ms_models, means_fr, oracle_mod):
+    g, o = ms_models
+    mg = ssw.MsMgau(g)
+    rng = np.random.default_rng(9)
+    feats = synth_features(means_fr, 4, 2)
+    for t, dens in enumerate((0.01, 0.2, 1.0, 0.05)):
+        vec = np.zeros((o.n_sen + 31) // 32, np.uint32)
+        for s in np.flatnonzero(rng.random(o.n_sen) < dens):
+            vec[s // 32] |= np.uint32(1 << (s % 32))
+        lst = oracle_mod.flags2list(vec, o.n_sen)
+        got = mg.frame_eval(feats[t], t, compallsen=False, senone_active=lst)
+        ref = o.ms_frame_eval(feats[t], t, compallsen=False, senone_active=lst)
+        assert np.array_equal(got, ref), t
+    mg.free()
