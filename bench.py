@@ -151,12 +151,24 @@ def main():
     ab = algorithmic_bytes(model.n_sen, model.n_feat, model.topn, model.n_cb, model.n_density,
                            model.veclen_total, n_frames)
     names = ("topn_kernel", "senone_kernel")
-    dom = int(np.argmax(k_ms))
-    achieved = ab[names[dom]] * n_frames / (k_ms[dom] * 1e-3) / 1e9
     total_frames = n_frames * world * args.steps
     fps = total_frames / elapsed
     ops_per_frame = model.n_cb * model.n_feat * (model.n_density + model.topn) * 13 * 4
     flagged, pairs = model.last_stats()
+    # roofline of the hot path = the launches of one step (top-N pass incl. its exact fix-up,
+    # senone pass); algorithmic bytes = SURVEY 8(d)'s 72,345 B/frame x frames per launch set
+    path_ms = float(k_ms.sum())
+    achieved = ab["path"] * n_frames / (path_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")
+    if os.path.exists(tfile) and n_frames == 4096 and args.model == "en-us":
+        with open(tfile) as fh:      # PMC counters cannot be read from inside this process;
+            traffic = json.load(fh)["hbm_bytes"]  # committed rocprofv3 measurement of this step
+    per_kernel = {
+        nm: {"ms": float(k_ms[i]), "algorithmic_bytes_per_frame": ab[nm],
+             "achieved_GBps": ab[nm] * n_frames / (k_ms[i] * 1e-3) / 1e9,
+             "hbm_frac": ab[nm] * n_frames / (k_ms[i] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        for i, nm in enumerate(names)}
     out = {
         "metric": "senone-frames/sec (en-us PTM)",
         "value": fps,
@@ -175,12 +187,11 @@ def main():
                                f"39-dim features resident in HBM, compallsen=yes, topn=4",
                    "n_sen": model.n_sen, "n_cb": model.n_cb, "parallelism": f"utt-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": names[dom], "kernel_ms": float(k_ms[dom]),
-                     "algorithmic_bytes_per_frame": ab[names[dom]]},
-        "kernels_ms": {"topn_kernel": float(k_ms[0]), "senone_kernel": float(k_ms[1])},
-        "path_algorithmic_bytes_per_frame": ab["path"],
-        "path_hbm_frac": fps / world * ab["path"] / (HBM_PEAK_GBS * 1e9),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "PTM path of one step: ptm_topn_frames + ptm_topn_fixup + ptm_senone",
+                     "kernel_ms": path_ms, "algorithmic_bytes_per_frame": ab["path"],
+                     "note": "VALU-issue bound, not HBM bound (DESIGN.md section 5): see valu_frac"},
+        "kernels": per_kernel,
         "valu_frac": fps / world * ops_per_frame / VALU_PEAK_OPS,
         "exact_pass_share": flagged / max(pairs, 1),
     }

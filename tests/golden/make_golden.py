@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.json from the CPU oracle.
+
+The oracle itself is pinned to outputs of the real reference library (DESIGN.md section 2:
+test_log_shifted.c, _test_fe.res, SURVEY Appendix C incl. the goforward alignment); these
+fixtures freeze what that pinned oracle produces on the synthetic workloads of BASELINE.json so
+that (a) an accidental change of the oracle is caught on CPU and (b) the GPU tests can check
+full-size configs without paying for the oracle every time.  Inputs are regenerated from seeds
+(SURVEY 8(d) LCG) on both sides; only checksums and a few rows are stored.
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+from soundswallower_amd.synth import (lcg_uniform, read_raw_means, synth_alignment_task,  # noqa: E402
+                                      synth_features)
+
+MODEL = os.path.join(ROOT, "soundswallower_amd", "model")
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def config2(n_utts=16, n_frames=256):
+    m = O.Model(os.path.join(MODEL, "en-us"))
+    means = read_raw_means(os.path.join(MODEL, "en-us"))
+    feats = np.concatenate([synth_features(means, n_frames, 12345 + u) for u in range(n_utts)])
+    out = {"feats_crc": crc(feats)}
+    per_utt = np.concatenate([m.ptm_score_utt(feats[u * n_frames:(u + 1) * n_frames])
+                              for u in range(n_utts)])
+    one = m.ptm_score_utt(feats)
+    out["utt16x256"] = {"crc": crc(per_utt), "frame_crc": [crc(r) for r in per_utt[::64]],
+                        "row0_first16": per_utt[0, :16].tolist()}
+    out["utt1x4096"] = {"crc": crc(one), "n_rows_differ_from_16x256":
+                        int((one != per_utt).any(axis=1).sum())}
+    return out
+
+
+def config3(n_utts=4, n_frames=1000, n_phones=150):
+    m = O.Model(os.path.join(MODEL, "en-us"))
+    means = read_raw_means(os.path.join(MODEL, "en-us"))
+    res = []
+    for u in range(n_utts):
+        feats = synth_features(means, n_frames, 12345 + u)
+        scr = m.ptm_score_utt(feats)
+        senid, tmat, _ = synth_alignment_task(m.sseq, m.phone_ssid, m.phone_tmat, m.n_ciphone,
+                                              n_phones, 777 + u)
+        rv, st, ph = m.state_align(scr, senid, tmat)
+        res.append({"rv": rv, "states_crc": crc(st), "phones_crc": crc(ph),
+                    "first_phones": ph[:4].tolist(), "senscr_crc": crc(scr)})
+    return res
+
+
+if __name__ == "__main__":
+    g = {"config2_en_us_ptm": config2(), "config3_align": config3()}
+    with open(os.path.join(ROOT, "tests", "golden", "synthetic_oracle.json"), "w") as fh:
+        json.dump(g, fh, indent=1)
+    print(json.dumps(g)[:400])

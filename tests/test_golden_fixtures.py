@@ -1,0 +1,78 @@
+"""Committed golden checksums (tests/golden/synthetic_oracle.json, made by make_golden.py from
+the reference-pinned oracle): the oracle must keep reproducing them on CPU, and the GPU path
+must match them at the full BASELINE config sizes."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from soundswallower_amd.synth import synth_alignment_task, synth_features
+from tests.conftest import ROOT
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "synthetic_oracle.json")) as fh:
+        return json.load(fh)
+
+
+def test_oracle_reproduces_golden_config2_sample(golden, orc_en, means_en):
+    g = golden["config2_en_us_ptm"]["utt16x256"]
+    feats = synth_features(means_en, 256, 12345)          # utterance 0 of the batch
+    scr = orc_en.ptm_score_utt(feats)
+    assert scr[0, :16].tolist() == g["row0_first16"]
+    assert [crc(r) for r in scr[::64]] == g["frame_crc"][:4]
+
+
+def test_oracle_reproduces_golden_alignment(golden, orc_en, means_en):
+    g = golden["config3_align"][0]
+    feats = synth_features(means_en, 1000, 12345)
+    scr = orc_en.ptm_score_utt(feats)
+    assert crc(scr) == g["senscr_crc"]
+    senid, tmat, _ = synth_alignment_task(orc_en.sseq, orc_en.phone_ssid, orc_en.phone_tmat,
+                                          orc_en.n_ciphone, 150, 777)
+    rv, st, ph = orc_en.state_align(scr, senid, tmat)
+    assert rv == g["rv"] and crc(st) == g["states_crc"] and ph[:4].tolist() == g["first_phones"]
+
+
+@pytest.mark.gpu
+def test_gpu_matches_golden_config2_both_layouts(golden, gpu_en, means_en):
+    g = golden["config2_en_us_ptm"]
+    feats = np.concatenate([synth_features(means_en, 256, 12345 + u) for u in range(16)])
+    assert crc(feats) == g["feats_crc"]
+    a = gpu_en.score_batch(feats, np.arange(17, dtype=np.int32) * 256)
+    assert crc(a) == g["utt16x256"]["crc"]
+    b = gpu_en.score_batch(feats, np.array([0, 4096], np.int32))
+    assert crc(b) == g["utt1x4096"]["crc"]
+    # the two layouts differ exactly where the reference's carried top-N history says they do
+    assert int((a != b).any(axis=1).sum()) == g["utt1x4096"]["n_rows_differ_from_16x256"]
+
+
+@pytest.mark.gpu
+def test_gpu_matches_golden_config3_alignment(golden, gpu_en, orc_en, means_en):
+    """BASELINE config 3 shape (1000 frames, 150 phones), 4 utterances in one batch."""
+    feats = np.concatenate([synth_features(means_en, 1000, 12345 + u) for u in range(4)])
+    frame_off = (np.arange(5) * 1000).astype(np.int32)
+    scr = gpu_en.score_batch(feats, frame_off)
+    senids, tmats = [], []
+    for u in range(4):
+        s, t, _ = synth_alignment_task(orc_en.sseq, orc_en.phone_ssid, orc_en.phone_tmat,
+                                       orc_en.n_ciphone, 150, 777 + u)
+        senids.append(s)
+        tmats.append(t)
+    d = gpu_en.to_device(scr)
+    try:
+        st, status = gpu_en.align_batch(d, frame_off, (np.arange(5) * 150).astype(np.int32),
+                                        np.concatenate(senids), np.concatenate(tmats))
+    finally:
+        gpu_en.device_free(d)
+    for u, g in enumerate(golden["config3_align"]):
+        assert crc(scr[u * 1000:(u + 1) * 1000]) == g["senscr_crc"]
+        assert (status[u] == 0) == (g["rv"] == 0)
+        assert crc(st[u * 450:(u + 1) * 450]) == g["states_crc"]
