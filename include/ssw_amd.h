@@ -190,6 +190,17 @@ const ssw_align_entry_t *ssw_state_align_search_phones(const ssw_state_align_sea
                                                        int32_t *n);
 void ssw_state_align_search_free(ssw_state_align_search_t *s);
 
+/* ------------------------------------------------------------------------------------ */
+/* Dynamic features on the device: feat_s2mfc2feat_live for whole    */
+/* utterances with feat = 1s_c_d_dd, cmn = batch ("current"), no varnorm / agc / lda       */
+/* (src/feat.c:977-1008, 589-632; src/cmn.c:168-200).  d_cep [n_frames][ncep] MFCC rows     */
+/* -> d_out [n_frames][3*ncep] = cep | delta | delta-delta, i.e. the 0-12/13-25/26-38       */
+/* stream split the scorers read.  Bit-exact float32, synchronous on `stream`.            */
+/* ------------------------------------------------------------------------------------ */
+int ssw_feat_batch(ssw_model_t *m, const float *d_cep, int32_t n_frames,
+                   const int32_t *utt_off, int32_t n_utts, int32_t ncep, float *d_out,
+                   void *stream);
+
 /* device-memory helpers so a C caller needs no HIP headers */
 void *ssw_device_malloc(size_t nbytes);
 void ssw_device_free(void *d_ptr);

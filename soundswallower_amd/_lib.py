@@ -107,6 +107,7 @@ def lib() -> C.CDLL:
     L.ssw_state_align_search_phones.restype = C.POINTER(SswAlignEntry)
     L.ssw_state_align_search_phones.argtypes = [vp, C.POINTER(i32)]
     L.ssw_state_align_search_free.argtypes = [vp]
+    L.ssw_feat_batch.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.ssw_device_malloc.restype = vp
     L.ssw_device_malloc.argtypes = [sz]
     L.ssw_device_free.argtypes = [vp]

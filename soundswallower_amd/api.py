@@ -179,6 +179,27 @@ class Model:
                                                n_parent), "ssw_alignment_propagate")
         return out
 
+    # ---- dynamic features ------------------------------------------------------------
+    def feat_batch(self, cep, utt_off=None) -> np.ndarray:
+        """Batch CMN + 1s_c_d_dd on the GPU: host MFCC [n][ncep] -> host features [n][3*ncep]."""
+        cep = np.ascontiguousarray(cep, np.float32)
+        n, ncep = cep.shape
+        off = (np.array([0, n], np.int32) if utt_off is None
+               else np.ascontiguousarray(utt_off, np.int32))
+        out = np.zeros((n, 3 * ncep), np.float32)
+        if n == 0:
+            return out
+        d_in = self.to_device(cep)
+        d_out = _check(self._L.ssw_device_malloc(out.nbytes), "ssw_device_malloc")
+        try:
+            _check(self._L.ssw_feat_batch(self._m, d_in, n, _ptr(off), len(off) - 1, ncep, d_out,
+                                          None), "ssw_feat_batch")
+            _check(self._L.ssw_memcpy_d2h(_ptr(out), d_out, out.nbytes), "ssw_memcpy_d2h")
+        finally:
+            self._L.ssw_device_free(d_in)
+            self._L.ssw_device_free(d_out)
+        return out
+
     # ---- device memory (no torch needed) --------------------------------------------
     def to_device(self, arr: np.ndarray) -> int:
         arr = np.ascontiguousarray(arr)

@@ -1212,6 +1212,62 @@ ms_senone_kernel(SenoneParams P)
 }
 
 /* ---------------------------------------------------------------------------------- */
+/* K4: dynamic features, whole utterances: batch CMN + 1s_c_d_dd                        */
+/* ---------------------------------------------------------------------------------- */
+/* feat_s2mfc2feat_block_utt for feat = 1s_c_d_dd, cmn = batch (src/feat.c:977-1008, 589-632;
+ * src/cmn.c:168-200).  One wave per utterance, lane = cepstral dimension for the mean (the
+ * reference accumulates sum[i] += mfc[f][i] in float32, frame after frame, skipping frames with
+ * c0 < 0: that order is kept, 13 independent chains), then lanes sweep (frame, dimension)
+ * pairs for the subtraction and the deltas:
+ *   d[i]  = c[t+2][i] - c[t-2][i],   dd[i] = (c[t+3][i] - c[t-1][i]) - (c[t+1][i] - c[t-3][i])
+ * with the first / last (mean-subtracted) frame replicated 3 times at the edges. */
+struct FeatParams {
+    const float *cep; /* [n_frames][ncep] */
+    const int *utt_off;
+    float *out;       /* [n_frames][3*ncep] */
+    int n_utts, ncep;
+};
+
+__global__ void __launch_bounds__(64)
+feat_1s_c_d_dd_kernel(FeatParams P)
+{
+    __shared__ float s_mean[64];
+    const int u = blockIdx.x, lane = threadIdx.x, C = P.ncep;
+    const int t0 = P.utt_off[u], n = P.utt_off[u + 1] - t0;
+    if (n <= 0)
+        return;
+    const float *cep = P.cep + (size_t)t0 * C;
+    if (lane < C) {
+        float sum = 0.0f;
+        int nframe = 0;
+        for (int f = 0; f < n; ++f) {
+            const float *row = cep + (size_t)f * C;
+            if (row[0] < 0) /* "skip zero energy frames", src/cmn.c:186-188 */
+                continue;
+            sum += row[lane];
+            ++nframe;
+        }
+        s_mean[lane] = sum / nframe; /* float / int, src/cmn.c:197 */
+    }
+    __syncthreads();
+    float *out = P.out + (size_t)t0 * 3 * C;
+    const int total = n * C;
+    for (int idx = lane; idx < total; idx += 64) {
+        const int t = idx / C, i = idx - t * C;
+        const float mean = s_mean[i];
+#define CEP(tt) (cep[(size_t)((tt) < 0 ? 0 : ((tt) >= n ? n - 1 : (tt))) * C + i] - mean)
+        const float c0 = CEP(t);
+        const float d = CEP(t + 2) - CEP(t - 2);
+        const float d1 = CEP(t + 3) - CEP(t - 1);
+        const float d2 = CEP(t + 1) - CEP(t - 3);
+#undef CEP
+        out[(size_t)t * 3 * C + i] = c0;
+        out[(size_t)t * 3 * C + C + i] = d;
+        out[(size_t)t * 3 * C + 2 * C + i] = d1 - d2;
+    }
+}
+
+/* ---------------------------------------------------------------------------------- */
 /* K2: forced-alignment Viterbi, one wave per utterance                                 */
 /* ---------------------------------------------------------------------------------- */
 
@@ -2761,6 +2817,50 @@ extern "C" void
 ssw_state_align_search_free(ssw_state_align_search_t *s)
 {
     delete s;
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* dynamic features                                                 */
+/* ---------------------------------------------------------------------------------- */
+extern "C" int
+ssw_feat_batch(ssw_model_t *m, const float *d_cep, int32_t n_frames, const int32_t *utt_off,
+               int32_t n_utts, int32_t ncep, float *d_out, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n_frames == 0 || n_utts == 0)
+        return 0;
+    if (m->device == SSW_DEVICE_NONE) {
+        ssw_set_error("model was loaded with device = SSW_DEVICE_NONE: no GPU, no CPU fallback");
+        return -1;
+    }
+    if (ncep < 1 || ncep > 64 || n_frames < 0 || n_utts < 0 || utt_off == NULL || utt_off[0] != 0
+        || utt_off[n_utts] != n_frames) {
+        ssw_set_error("bad arguments to ssw_feat_batch");
+        return -1;
+    }
+    HIP_OK(hipSetDevice(m->device));
+    int *d_off = NULL;
+    HIP_OK(hipMalloc((void **)&d_off, sizeof(int) * ((size_t)n_utts + 1)));
+    hipError_t e = hipMemcpyAsync(d_off, utt_off, sizeof(int) * ((size_t)n_utts + 1),
+                                  hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        FeatParams F;
+        F.cep = d_cep;
+        F.utt_off = d_off;
+        F.out = d_out;
+        F.n_utts = n_utts;
+        F.ncep = ncep;
+        hipLaunchKernelGGL(feat_1s_c_d_dd_kernel, dim3(n_utts), dim3(64), 0, st, F);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    (void)hipFree(d_off);
+    if (e != hipSuccess) {
+        ssw_set_error("ssw_feat_batch: %s", hipGetErrorString(e));
+        return -1;
+    }
+    return 0;
 }
 
 /* ---------------------------------------------------------------------------------- */
