@@ -191,6 +191,31 @@ const ssw_align_entry_t *ssw_state_align_search_phones(const ssw_state_align_sea
 void ssw_state_align_search_free(ssw_state_align_search_t *s);
 
 /* ------------------------------------------------------------------------------------ */
+/* Lexicon glue (host C): what decoder_alignment needs to go from       */
+/* words + word windows to the per-phone rows state_align_search_init reads.               */
+/* ------------------------------------------------------------------------------------ */
+typedef struct ssw_dict_s ssw_dict_t;
+/* dict_init (src/dict.c): text dictionaries "word PH PH ...", main then filler; <s>, </s>,
+ * <sil> always exist.  Words with unknown phones are skipped. */
+ssw_dict_t *ssw_dict_load(const ssw_model_t *m, const char *dict_path, const char *filler_path);
+void ssw_dict_free(ssw_dict_t *d);
+int32_t ssw_dict_size(const ssw_dict_t *d);
+/* CI phone ids of a word's pronunciation; returns its length or -1 when unknown */
+int32_t ssw_dict_pron(const ssw_dict_t *d, const char *word, int32_t *ciphones, int32_t max);
+const char *ssw_ciphone_name(const ssw_model_t *m, int32_t ci);
+/* bin_mdef_phone_id_nearest (src/bin_mdef.c:666-720); pos: 0 internal, 1 begin, 2 end, 3 single */
+int32_t ssw_phone_id_nearest(const ssw_model_t *m, int32_t b, int32_t l, int32_t r, int32_t pos);
+/* alignment_add_word per word + alignment_populate (src/ps_alignment.c:114-247): returns the
+ * number of phones written (ssid, tmatid, and optionally cipid, parent word, and the word's
+ * start/duration copied to each phone, which is what state_align_search_init turns into
+ * sf/ef), or -1 (unknown word, too many phones). */
+int32_t ssw_alignment_populate(const ssw_model_t *m, const ssw_dict_t *d, int32_t n_words,
+                               const char *const *words, const int32_t *start,
+                               const int32_t *duration, int32_t max_phones, int32_t *ssid,
+                               int32_t *tmatid, int32_t *cipid, int32_t *parent,
+                               int32_t *ph_start, int32_t *ph_duration);
+
+/* ------------------------------------------------------------------------------------ */
 /* Dynamic features on the device: feat_s2mfc2feat_live for whole    */
 /* utterances with feat = 1s_c_d_dd, cmn = batch ("current"), no varnorm / agc / lda       */
 /* (src/feat.c:977-1008, 589-632; src/cmn.c:168-200).  d_cep [n_frames][ncep] MFCC rows     */

@@ -107,6 +107,19 @@ def lib() -> C.CDLL:
     L.ssw_state_align_search_phones.restype = C.POINTER(SswAlignEntry)
     L.ssw_state_align_search_phones.argtypes = [vp, C.POINTER(i32)]
     L.ssw_state_align_search_free.argtypes = [vp]
+    L.ssw_dict_load.restype = vp
+    L.ssw_dict_load.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.ssw_dict_free.argtypes = [vp]
+    L.ssw_dict_size.restype = i32
+    L.ssw_dict_size.argtypes = [vp]
+    L.ssw_dict_pron.restype = i32
+    L.ssw_dict_pron.argtypes = [vp, C.c_char_p, vp, i32]
+    L.ssw_ciphone_name.restype = C.c_char_p
+    L.ssw_ciphone_name.argtypes = [vp, i32]
+    L.ssw_phone_id_nearest.restype = i32
+    L.ssw_phone_id_nearest.argtypes = [vp, i32, i32, i32, i32]
+    L.ssw_alignment_populate.restype = i32
+    L.ssw_alignment_populate.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.ssw_feat_batch.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.ssw_device_malloc.restype = vp
     L.ssw_device_malloc.argtypes = [sz]

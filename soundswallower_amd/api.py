@@ -326,3 +326,51 @@ class MsMgau(PtmMgau):
         self._g = self._L.ssw_ms_mgau_init(model._m)
         if not self._g:
             raise SswError("ssw_ms_mgau_init: " + _lib.last_error())
+
+
+class Lexicon:
+    """Pronunciation dictionary + alignment_populate on the host (ssw_dict_load,
+    ssw_alignment_populate): words and their windows -> the per-phone rows the aligner takes."""
+
+    def __init__(self, model: Model, dict_path=None, filler_path=None):
+        self._L = _lib.lib()
+        self.model = model
+        enc = lambda s: None if s is None else os.fsencode(s)
+        self._d = self._L.ssw_dict_load(model._m, enc(dict_path), enc(filler_path))
+        if not self._d:
+            raise SswError("ssw_dict_load: " + _lib.last_error())
+
+    def __len__(self):
+        return int(self._L.ssw_dict_size(self._d))
+
+    def pron(self, word: str):
+        buf = np.zeros(256, np.int32)
+        n = self._L.ssw_dict_pron(self._d, word.encode(), _ptr(buf), 256)
+        if n < 0:
+            raise KeyError(word)
+        return [self._L.ssw_ciphone_name(self.model._m, int(c)).decode() for c in buf[:n]]
+
+    def phone_id_nearest(self, b, l, r, pos):
+        return int(self._L.ssw_phone_id_nearest(self.model._m, int(b), int(l), int(r), int(pos)))
+
+    def populate(self, words, start=None, duration=None, max_phones=21845):
+        """Returns dict(ssid, tmatid, cipid, parent, start, duration) of int32 arrays."""
+        n = len(words)
+        arr = (C.c_char_p * n)(*[w.encode() for w in words])
+        st = None if start is None else np.ascontiguousarray(start, np.int32)
+        du = None if duration is None else np.ascontiguousarray(duration, np.int32)
+        out = {k: np.zeros(max_phones, np.int32)
+               for k in ("ssid", "tmatid", "cipid", "parent", "start", "duration")}
+        k = self._L.ssw_alignment_populate(self.model._m, self._d, n, arr, _ptr(st), _ptr(du),
+                                           max_phones, _ptr(out["ssid"]), _ptr(out["tmatid"]),
+                                           _ptr(out["cipid"]), _ptr(out["parent"]),
+                                           _ptr(out["start"]), _ptr(out["duration"]))
+        _check(k, "ssw_alignment_populate")
+        return {key: v[:k].copy() for key, v in out.items()}
+
+    def free(self):
+        if getattr(self, "_d", None):
+            self._L.ssw_dict_free(self._d)
+            self._d = None
+
+    __del__ = free

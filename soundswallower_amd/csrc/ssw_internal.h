@@ -34,6 +34,11 @@ typedef struct ssw_host_model_s {
     uint16_t *sseq;
     int16_t *sen2cb; /* bin_mdef sen2cimap */
     int32_t *phone_ssid, *phone_tmat;
+    /* context-dependent phone tree (cd_tree_t, bin_mdef.h:103-114), host byte order */
+    int32_t n_cd_tree;
+    struct ssw_cd_node_s { int16_t ctx, n_down; int32_t down_or_pid; } *cd_tree;
+    char **ciname;       /* [n_ciphone] */
+    uint8_t *ci_filler;  /* [n_ciphone] */
     /* tmat */
     uint8_t *tp;
     int32_t tp_n_tmat, tp_n_state;

@@ -1777,6 +1777,12 @@ ssw_model_free(ssw_model_t *m)
     delete m;
 }
 
+extern "C" const ssw_host_model_t *
+ssw_model_host(const ssw_model_t *m)
+{
+    return m->h;
+}
+
 extern "C" int
 ssw_model_info(const ssw_model_t *m, ssw_model_info_t *o)
 {

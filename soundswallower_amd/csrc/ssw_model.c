@@ -471,6 +471,7 @@ load_mdef(ssw_host_model_t *h, const char *path)
     /* CI names: n_ciphone NUL-terminated strings, block padded to 4 bytes */
     names = at = r.at;
     h->sil = -1;
+    h->ciname = (char **)calloc((size_t)h->n_ciphone, sizeof(char *));
     for (i = 0; i < h->n_ciphone; ++i) {
         const char *nm = (const char *)r.base + at;
         size_t l = strnlen(nm, r.size - at);
@@ -478,9 +479,20 @@ load_mdef(ssw_host_model_t *h, const char *path)
             goto trunc;
         if (l == 3 && memcmp(nm, "SIL", 3) == 0)
             h->sil = i;
+        h->ciname[i] = (char *)malloc(l + 1);
+        memcpy(h->ciname[i], nm, l + 1);
         at += l + 1;
     }
     at = names + ((at - names + 3) / 4) * 4;
+    if (at + (size_t)n_tree * 8 > r.size)
+        goto trunc;
+    h->n_cd_tree = n_tree;
+    h->cd_tree = (struct ssw_cd_node_s *)malloc(sizeof(*h->cd_tree) * (size_t)(n_tree ? n_tree : 1));
+    for (i = 0; i < n_tree; ++i) {
+        h->cd_tree[i].ctx = (int16_t)peek16(&r, at + 8 * (size_t)i);
+        h->cd_tree[i].n_down = (int16_t)peek16(&r, at + 8 * (size_t)i + 2);
+        h->cd_tree[i].down_or_pid = (int32_t)peek32(&r, at + 8 * (size_t)i + 4);
+    }
     phones = at + (size_t)n_tree * 8;
     at = phones + (size_t)h->n_phone * 12;
     if (at + 4 > r.size)
@@ -498,6 +510,9 @@ load_mdef(ssw_host_model_t *h, const char *path)
     h->sen2cb = (int16_t *)malloc(sizeof(int16_t) * (size_t)h->n_sen);
     for (i = 0; i < h->n_sen; ++i)
         h->sen2cb[i] = -1;
+    h->ci_filler = (uint8_t *)calloc((size_t)h->n_ciphone, 1);
+    for (i = 0; i < h->n_ciphone && i < h->n_phone; ++i)
+        h->ci_filler[i] = r.base[phones + (size_t)i * 12 + 8]; /* info.ci.filler */
     for (i = 0; i < h->n_phone; ++i) {
         size_t e = phones + (size_t)i * 12;
         int base = (i < h->n_ciphone) ? i : r.base[e + 9]; /* first context byte = base phone */
@@ -766,6 +781,14 @@ ssw_host_model_free(ssw_host_model_t *h)
     free(h->sen2cb);
     free(h->phone_ssid);
     free(h->phone_tmat);
+    free(h->cd_tree);
+    free(h->ci_filler);
+    if (h->ciname) {
+        int i;
+        for (i = 0; i < h->n_ciphone; ++i)
+            free(h->ciname[i]);
+        free(h->ciname);
+    }
     free(h->tp);
     free(h->ptm_mixw);
     free(h->ms_pdf);

@@ -210,3 +210,36 @@ def test_mgau_vtable_compallsen_no(gpu_en, orc_en, oracle_mod, means_en):
         g.frame_idx = t + 1
         orc_en.ptm_set_frame_idx(t + 1)
     g.free()
+
+
+def test_goforward_from_words_with_product_glue(gpu_en, oracle_mod):
+    """Words + word windows -> Lexicon.populate (host C) -> StateAlignSearch (GPU), features
+    from the device feature kernel: the product's own pieces end to end, against the reference's
+    recorded alignment."""
+    import os
+    from tests.conftest import MODEL_ROOT, ROOT
+    from tests.test_oracle_e2e_goforward import REF_WORDS, _parse_ref
+    pcm = np.fromfile(os.path.join(ROOT, "tests", "golden", "goforward.raw"), dtype="<i2")
+    cep = oracle_mod.fe_mfcc(pcm, nfilt=20, lowerf=130, upperf=3700, lifter=22, remove_noise=True,
+                             transform="dct")         # the MFCC front end is outside the path
+    feats = gpu_en.feat_batch(cep)
+    d = os.path.join(MODEL_ROOT, "en-us")
+    lex = ssw.Lexicon(gpu_en, os.path.join(d, "dict.txt"), os.path.join(d, "noisedict.txt"))
+    rows = lex.populate([w for (w, _, _, _) in REF_WORDS], [s for (_, s, _, _) in REF_WORDS],
+                        [dd for (_, _, dd, _) in REF_WORDS])
+    g = ssw.PtmMgau(gpu_en)
+    s = ssw.StateAlignSearch(gpu_en, g, rows["ssid"], rows["tmatid"], rows["start"],
+                             rows["duration"])
+    s.start()
+    for t in range(len(feats)):
+        s.step(feats[t], t)
+    s.finish()
+    ph = s.phones()
+    ref = _parse_ref()
+    # boundaries must equal the reference's; scores too, because the batch scorer's reset
+    # history does not change any senone score on this utterance
+    assert [(int(a), int(b)) for a, b, _ in ph] == [(r[1], r[2]) for r in ref]
+    assert [int(c) for _, _, c in ph] == [r[3] for r in ref]
+    s.free()
+    g.free()
+    lex.free()
