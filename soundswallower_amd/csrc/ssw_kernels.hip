@@ -102,15 +102,16 @@ struct ChainParams {
     const float *rec;     /* [n_cb][n_feat][n_density][SSW_REC_FLOATS] */
     const float *feats;   /* [n_frames][featdim] */
     const int *utt_off;   /* [n_utts+1] (chain mode) */
-    const int *work;      /* fix-up mode: [n_work] packed (frame << 8 | cbf) run heads */
+    const uint32_t *work; /* fix-up mode: list of flagged pairs, entry = t*n_cbf + cbf */
+    const unsigned *work_count; /* fix-up mode: entries in work[] (device side) */
+    const uint32_t *utt_start;  /* fix-up mode: bit per frame, set at an utterance's first frame */
     const uint32_t *carry_pk; /* optional [n_utts][n_cb*n_feat] packed cw order to start from */
     const uint8_t *cb_active; /* optional [n_cb]: 0 = only re-score the carried codewords
                                * (ptm_mgau_codebook_eval skips eval_cb, src/ptm_mgau.c:245-251) */
     uint32_t *topn_cw;    /* [n_frames][n_cb*n_feat] 4 x uint8 packed */
     int4 *topn_sc;        /* [n_frames][n_cb*n_feat] raw scores */
     const uint32_t *flags;/* fix-up mode: bit per (frame, cbf) */
-    const int *frame_utt_start; /* fix-up mode: [n_frames] first frame of the frame's utterance */
-    int n_utts, n_cbf, n_feat, featdim, ds, n_work, n_frames, frame_base;
+    int n_utts, n_cbf, n_feat, featdim, ds, n_frames, frame_base;
     int featoff[SSW_MAX_FEAT];
 };
 
@@ -330,81 +331,60 @@ ptm_topn_chain_kernel(ChainParams P)
     }
 }
 
-/* Fix-up pass behind ptm_topn_frames_kernel: a persistent grid of waves sweeps the flag bitset
- * (bit t*n_cbf + cbf = "the history-free result of this (frame, chain) pair is not proven
- * order-independent").  The head of every run of consecutive flagged frames of a chain is
- * re-done exactly: carried order = the previous frame's (final) result, or the reset state at
- * an utterance start; the run is walked in frame order.  ds == 1 only. */
+/* Fix-up pass behind ptm_topn_frames_kernel.  The frames kernel appends every pair it could not
+ * prove order-independent to a work list (and sets bit t*n_cbf + cbf of the flag bitset); one
+ * wave takes one list entry.  An entry that heads a run of consecutive flagged frames of its
+ * chain re-does the run exactly, in frame order: carried order = the previous frame's (final)
+ * result, or the reset state at an utterance start (utt_start: bit per frame).  Entries inside
+ * a run are skipped, their head covers them.  ds == 1 only. */
+__device__ __forceinline__ bool
+bit_test(const uint32_t *bits, long long i)
+{
+    return (bits[i >> 5] >> (i & 31)) & 1u;
+}
+
 template <int VECLEN, int NDL, int TOPN>
 __global__ void __launch_bounds__(64)
-ptm_topn_fixup_kernel(ChainParams P, int n_words, unsigned long long *n_fixed)
+ptm_topn_fixup_kernel(ChainParams P, unsigned long long *n_fixed)
 {
     const int lane = threadIdx.x;
     float mean[NDL][VECLEN], var[NDL][VECLEN], det[NDL];
     int loaded_cbf = -1;
     unsigned long long fixed = 0;
-    constexpr int WPW = 8; /* flag words per wave and sweep step: small, so that flagged pairs
-                            * spread over many waves and the pass is one item deep */
-    for (int chunk = blockIdx.x; chunk * WPW < n_words; chunk += gridDim.x) {
-        int widx = chunk * WPW + lane;
-        uint32_t word = (lane < WPW && widx < n_words) ? P.flags[widx] : 0u;
-        unsigned long long wmask = __ballot(word != 0);
-        while (wmask) {
-            int l = __builtin_ctzll(wmask);
-            wmask &= wmask - 1;
-            uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)word, l);
-            while (w) {
-                int b = __builtin_ctz(w);
-                w &= w - 1;
-                long long bit = ((long long)(chunk * WPW + l) << 5) + b;
-                int t = (int)(bit / P.n_cbf);
-                int cbf = (int)(bit - (long long)t * P.n_cbf);
-                /* utterance of frame t: last u with utt_off[u] <= t */
-                int lo = 0, hi = P.n_utts;
-                while (hi - lo > 1) {
-                    int mid = (lo + hi) >> 1;
-                    if (P.utt_off[mid] <= t)
-                        lo = mid;
-                    else
-                        hi = mid;
-                }
-                const int ustart = P.utt_off[lo], uend = P.utt_off[lo + 1];
-                if (t > ustart) { /* only run heads start a walk */
-                    long long pbit = bit - P.n_cbf;
-                    if ((P.flags[pbit >> 5] >> (pbit & 31)) & 1u)
-                        continue;
-                }
-                if (cbf != loaded_cbf) {
-                    load_lane_gaussians<VECLEN, NDL>(
-                        P.rec + (size_t)cbf * (NDL * 64) * SSW_REC_FLOATS, lane, mean, var, det);
-                    loaded_cbf = cbf;
-                }
-                int Lc[TOPN], Ls[TOPN];
-                if (t > ustart) {
-                    uint32_t pk = P.topn_cw[(size_t)(t - 1) * P.n_cbf + cbf];
+    const unsigned n_work = *P.work_count;
+    for (unsigned i = blockIdx.x; i < n_work; i += gridDim.x) {
+        const uint32_t bit = P.work[i];
+        const int t = (int)(bit / (uint32_t)P.n_cbf);
+        const int cbf = (int)(bit - (uint32_t)t * (uint32_t)P.n_cbf);
+        const bool at_start = bit_test(P.utt_start, t);
+        if (!at_start && bit_test(P.flags, (long long)bit - P.n_cbf))
+            continue; /* only run heads start a walk */
+        if (cbf != loaded_cbf) {
+            load_lane_gaussians<VECLEN, NDL>(P.rec + (size_t)cbf * (NDL * 64) * SSW_REC_FLOATS,
+                                             lane, mean, var, det);
+            loaded_cbf = cbf;
+        }
+        int Lc[TOPN], Ls[TOPN];
+        if (!at_start) {
+            uint32_t pk = P.topn_cw[(size_t)(t - 1) * P.n_cbf + cbf];
 #pragma unroll
-                    for (int k = 0; k < TOPN; ++k)
-                        Lc[k] = (pk >> (8 * k)) & 0xff;
-                } else {
+            for (int k = 0; k < TOPN; ++k)
+                Lc[k] = (pk >> (8 * k)) & 0xff;
+        } else {
 #pragma unroll
-                    for (int k = 0; k < TOPN; ++k)
-                        Lc[k] = k;
-                }
+            for (int k = 0; k < TOPN; ++k)
+                Lc[k] = k;
+        }
 #pragma unroll
-                for (int k = 0; k < TOPN; ++k)
-                    Ls[k] = INT_MIN;
-                const int f = cbf % P.n_feat;
-                for (int tt = t; tt < uend; ++tt) {
-                    if (tt > t) {
-                        long long nb = (long long)tt * P.n_cbf + cbf;
-                        if (!((P.flags[nb >> 5] >> (nb & 31)) & 1u))
-                            break;
-                    }
-                    chain_frame<VECLEN, NDL, TOPN>(P, tt, cbf, f, true, lane, mean, var, det, Lc,
-                                                   Ls);
-                    ++fixed;
-                }
-            }
+        for (int k = 0; k < TOPN; ++k)
+            Ls[k] = INT_MIN;
+        const int f = cbf % P.n_feat;
+        for (int tt = t; tt < P.n_frames; ++tt) {
+            if (tt > t
+                && (bit_test(P.utt_start, tt) || !bit_test(P.flags, (long long)tt * P.n_cbf + cbf)))
+                break;
+            chain_frame<VECLEN, NDL, TOPN>(P, tt, cbf, f, true, lane, mean, var, det, Lc, Ls);
+            ++fixed;
         }
     }
     if (lane == 0 && fixed)
@@ -439,6 +419,8 @@ struct FramesParams {
     uint32_t *topn_cw;
     int4 *topn_sc;
     uint32_t *flags;
+    uint32_t *work;       /* flagged pairs, appended as found; entry = t*n_cbf + cbf */
+    unsigned *work_count;
     int n_frames, n_cbf, n_feat, featdim;
     int featoff[SSW_MAX_FEAT];
 };
@@ -616,8 +598,10 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
             P.topn_cw[idx] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16)
                 | ((uint32_t)c[3] << 24);
             P.topn_sc[idx] = make_int4(s[0], s[1], s[2], s[3]);
-            if (!proven)
+            if (!proven) {
                 atomicOr(&P.flags[idx >> 5], 1u << (idx & 31));
+                P.work[atomicAdd(P.work_count, 1u)] = (uint32_t)idx;
+            }
         }
     }
 }
@@ -628,108 +612,96 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
  * first position i with dval >= dist[i]. */
 template <int VECLEN, int NDL, int TOPN>
 __global__ void __launch_bounds__(64)
-ms_topn_fixup_kernel(ChainParams P, int n_words, unsigned long long *n_fixed)
+ms_topn_fixup_kernel(ChainParams P, unsigned long long *n_fixed)
 {
     const int lane = threadIdx.x;
     float mean[NDL][VECLEN], var[NDL][VECLEN], det[NDL];
     int loaded_cbf = -1;
     unsigned long long fixed = 0;
-    constexpr int WPW = 8;
-    for (int chunk = blockIdx.x; chunk * WPW < n_words; chunk += gridDim.x) {
-        int widx = chunk * WPW + lane;
-        uint32_t word = (lane < WPW && widx < n_words) ? P.flags[widx] : 0u;
-        unsigned long long wmask = __ballot(word != 0);
-        while (wmask) {
-            int l = __builtin_ctzll(wmask);
-            wmask &= wmask - 1;
-            uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)word, l);
-            while (w) {
-                int b = __builtin_ctz(w);
-                w &= w - 1;
-                long long bit = ((long long)(chunk * WPW + l) << 5) + b;
-                int t = (int)(bit / P.n_cbf);
-                int cbf = (int)(bit - (long long)t * P.n_cbf);
-                if (cbf != loaded_cbf) {
-                    load_lane_gaussians<VECLEN, NDL>(
-                        P.rec + (size_t)cbf * (NDL * 64) * SSW_REC_FLOATS, lane, mean, var, det);
-                    loaded_cbf = cbf;
-                }
-                const int f = cbf % P.n_feat;
-                const float *xp = P.feats + (size_t)t * P.featdim + P.featoff[f];
-                float x[VECLEN];
-#pragma unroll
-                for (int j = 0; j < VECLEN; ++j)
-                    x[j] = xp[j];
-                float dvl[NDL];
-#pragma unroll
-                for (int h = 0; h < NDL; ++h)
-                    dvl[h] = density<VECLEN>(x, mean[h], var[h], det[h]);
-                float Ld[TOPN];
-                int Lc[TOPN];
-#pragma unroll
-                for (int k = 0; k < TOPN; ++k) {
-                    Ld[k] = -2147483648.0f;
-                    Lc[k] = 0;
-                }
-                unsigned long long rem[NDL];
-#pragma unroll
-                for (int h = 0; h < NDL; ++h)
-                    rem[h] = ~0ull;
-                for (;;) {
-                    float thr = Ld[TOPN - 1];
-                    int cw = -1;
-#pragma unroll
-                    for (int h = NDL - 1; h >= 0; --h) {
-                        unsigned long long m = __ballot(dvl[h] >= thr) & rem[h];
-                        if (m != 0)
-                            cw = h * 64 + __builtin_ctzll(m);
-                    }
-                    if (cw < 0)
-                        break;
-#pragma unroll
-                    for (int h = 0; h < NDL; ++h) {
-                        if (h < (cw >> 6))
-                            rem[h] = 0;
-                        else if (h == (cw >> 6))
-                            rem[h] &= ~((2ull << (cw & 63)) - 1ull);
-                    }
-                    float dval = 0.0f;
-#pragma unroll
-                    for (int h = 0; h < NDL; ++h) {
-                        float tv = __builtin_bit_cast(
-                            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dvl[h]),
-                                                             cw & 63));
-                        dval = ((cw >> 6) == h) ? tv : dval;
-                    }
-                    int pos = 0;
-#pragma unroll
-                    for (int k = 0; k < TOPN - 1; ++k)
-                        pos += (Ld[k] > dval) ? 1 : 0;
-#pragma unroll
-                    for (int k = TOPN - 1; k >= 1; --k)
-                        if (k > pos) {
-                            Ld[k] = Ld[k - 1];
-                            Lc[k] = Lc[k - 1];
-                        }
-#pragma unroll
-                    for (int k = 0; k < TOPN; ++k)
-                        if (k == pos) {
-                            Ld[k] = dval;
-                            Lc[k] = cw;
-                        }
-                }
-                if (lane == 0) {
-                    uint32_t pk = 0;
-#pragma unroll
-                    for (int k = 0; k < TOPN; ++k)
-                        pk |= (uint32_t)(Lc[k] & 0xff) << (8 * k);
-                    P.topn_cw[(size_t)t * P.n_cbf + cbf] = pk;
-                    P.topn_sc[(size_t)t * P.n_cbf + cbf]
-                        = make_int4(ms_fden(Ld[0]), ms_fden(Ld[1]), ms_fden(Ld[2]), ms_fden(Ld[3]));
-                }
-                ++fixed;
-            }
+    const unsigned n_work = *P.work_count;
+    for (unsigned i = blockIdx.x; i < n_work; i += gridDim.x) {
+        const uint32_t bit = P.work[i];
+        const int t = (int)(bit / (uint32_t)P.n_cbf);
+        const int cbf = (int)(bit - (uint32_t)t * (uint32_t)P.n_cbf);
+        if (cbf != loaded_cbf) {
+            load_lane_gaussians<VECLEN, NDL>(
+                P.rec + (size_t)cbf * (NDL * 64) * SSW_REC_FLOATS, lane, mean, var, det);
+            loaded_cbf = cbf;
         }
+        const int f = cbf % P.n_feat;
+        const float *xp = P.feats + (size_t)t * P.featdim + P.featoff[f];
+        float x[VECLEN];
+#pragma unroll
+        for (int j = 0; j < VECLEN; ++j)
+            x[j] = xp[j];
+        float dvl[NDL];
+#pragma unroll
+        for (int h = 0; h < NDL; ++h)
+            dvl[h] = density<VECLEN>(x, mean[h], var[h], det[h]);
+        float Ld[TOPN];
+        int Lc[TOPN];
+#pragma unroll
+        for (int k = 0; k < TOPN; ++k) {
+            Ld[k] = -2147483648.0f;
+            Lc[k] = 0;
+        }
+        unsigned long long rem[NDL];
+#pragma unroll
+        for (int h = 0; h < NDL; ++h)
+            rem[h] = ~0ull;
+        for (;;) {
+            float thr = Ld[TOPN - 1];
+            int cw = -1;
+#pragma unroll
+            for (int h = NDL - 1; h >= 0; --h) {
+                unsigned long long m = __ballot(dvl[h] >= thr) & rem[h];
+                if (m != 0)
+                    cw = h * 64 + __builtin_ctzll(m);
+            }
+            if (cw < 0)
+                break;
+#pragma unroll
+            for (int h = 0; h < NDL; ++h) {
+                if (h < (cw >> 6))
+                    rem[h] = 0;
+                else if (h == (cw >> 6))
+                    rem[h] &= ~((2ull << (cw & 63)) - 1ull);
+            }
+            float dval = 0.0f;
+#pragma unroll
+            for (int h = 0; h < NDL; ++h) {
+                float tv = __builtin_bit_cast(
+                    float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dvl[h]),
+                                                     cw & 63));
+                dval = ((cw >> 6) == h) ? tv : dval;
+            }
+            int pos = 0;
+#pragma unroll
+            for (int k = 0; k < TOPN - 1; ++k)
+                pos += (Ld[k] > dval) ? 1 : 0;
+#pragma unroll
+            for (int k = TOPN - 1; k >= 1; --k)
+                if (k > pos) {
+                    Ld[k] = Ld[k - 1];
+                    Lc[k] = Lc[k - 1];
+                }
+#pragma unroll
+            for (int k = 0; k < TOPN; ++k)
+                if (k == pos) {
+                    Ld[k] = dval;
+                    Lc[k] = cw;
+                }
+        }
+        if (lane == 0) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int k = 0; k < TOPN; ++k)
+                pk |= (uint32_t)(Lc[k] & 0xff) << (8 * k);
+            P.topn_cw[(size_t)t * P.n_cbf + cbf] = pk;
+            P.topn_sc[(size_t)t * P.n_cbf + cbf]
+                = make_int4(ms_fden(Ld[0]), ms_fden(Ld[1]), ms_fden(Ld[2]), ms_fden(Ld[3]));
+        }
+        ++fixed;
     }
     if (lane == 0 && fixed)
         atomicAdd(n_fixed, fixed);
@@ -747,7 +719,8 @@ struct SenoneParams {
     const short4 *slot_sen;  /* [n_quads] senone ids of the 4 slots, -1 = padding */
     const uint8_t *logadd8;  /* [256] */
     uint32_t *flags;         /* optional: flag words of this frame are cleared for the next call */
-    unsigned long long *nfixed; /* optional: [0] running count of the fix-up pass, [1] last batch */
+    unsigned long long *nfixed; /* optional: [0] running count of the fix-up pass, [1] last batch,
+                                 * [2] fill count of the fix-up work list */
     int16_t *out;            /* [n_frames][n_sen] */
     int n_frames, n_cb, n_feat, n_density, n_sen, slot_stride, n_quads;
     int aw, zero; /* ms scorer: acoustic weight divisor, logmath zero at shift 10 */
@@ -808,6 +781,7 @@ ptm_senone_kernel(SenoneParams P)
         if (blockIdx.x == 0 && tid == 0) {
             P.nfixed[1] = P.nfixed[0];
             P.nfixed[0] = 0ull;
+            P.nfixed[2] = 0ull; /* the work list's fill count */
         }
     }
     __syncthreads();
@@ -1122,6 +1096,7 @@ ms_senone_kernel(SenoneParams P)
         if (t == 0 && tid == 0) {
             P.nfixed[1] = P.nfixed[0];
             P.nfixed[0] = 0ull;
+            P.nfixed[2] = 0ull; /* the work list's fill count */
         }
     }
     __syncthreads();
@@ -1580,7 +1555,9 @@ struct ssw_model_s {
     int4 *d_topn_sc;
     int *d_utt_off;
     uint32_t *d_flags;          /* bit per (frame, cbf): needs the exact pass */
-    unsigned long long *d_nfixed;
+    uint32_t *d_work;           /* the same pairs as a list (fix-up work items) */
+    uint32_t *d_utt_start;      /* bit per frame: first frame of an utterance */
+    unsigned long long *d_nfixed; /* [0],[1] exact-pass counters, [2] fill count of d_work */
     size_t ws_frames, ws_utts;
     std::vector<int32_t> *utt_cache; /* last uploaded utterance offsets */
     int force_exact;            /* SSW_PTM_EXACT=1: always run the sequential chain kernel */
@@ -1766,6 +1743,8 @@ ssw_model_free(ssw_model_t *m)
     (void)hipFree(m->d_topn_sc);
     (void)hipFree(m->d_utt_off);
     (void)hipFree(m->d_flags);
+    (void)hipFree(m->d_work);
+    (void)hipFree(m->d_utt_start);
     (void)hipFree(m->d_nfixed);
     delete m->utt_cache;
     (void)hipFree(m->d_feats);
@@ -1846,22 +1825,35 @@ ensure_score_ws(ssw_model_s *m, int n_frames, int n_utts)
         (void)hipFree(m->d_topn_cw);
         (void)hipFree(m->d_topn_sc);
         (void)hipFree(m->d_flags);
+        (void)hipFree(m->d_work);
+        (void)hipFree(m->d_utt_start);
         m->d_topn_cw = NULL;
         m->d_topn_sc = NULL;
         m->d_flags = NULL;
+        m->d_work = NULL;
+        m->d_utt_start = NULL;
         m->ws_frames = 0;
+        if (m->utt_cache)
+            m->utt_cache->clear(); /* d_utt_start has to be rebuilt */
+        if ((uint64_t)n_frames * (uint64_t)m->n_cbf > 0xffffffffull) {
+            ssw_set_error("batch of %d frames is too large (frames x codebooks x streams must fit 32 bits)",
+                          n_frames);
+            return -1;
+        }
         if (dev_alloc(&m->d_topn_cw, (size_t)n_frames * m->n_cbf) < 0
             || dev_alloc(&m->d_topn_sc, (size_t)n_frames * m->n_cbf) < 0
-            || dev_alloc(&m->d_flags, ((size_t)n_frames * m->n_cbf + 31) / 32 + 64) < 0)
+            || dev_alloc(&m->d_flags, ((size_t)n_frames * m->n_cbf + 31) / 32 + 64) < 0
+            || dev_alloc(&m->d_work, (size_t)n_frames * m->n_cbf) < 0
+            || dev_alloc(&m->d_utt_start, ((size_t)n_frames + 31) / 32 + 2) < 0)
             return -1;
         HIP_OK(hipMemset(m->d_flags, 0,
                          sizeof(uint32_t) * (((size_t)n_frames * m->n_cbf + 31) / 32 + 64)));
         m->ws_frames = (size_t)n_frames;
     }
     if (m->d_nfixed == NULL) {
-        if (dev_alloc(&m->d_nfixed, 2) < 0)
+        if (dev_alloc(&m->d_nfixed, 4) < 0)
             return -1;
-        HIP_OK(hipMemset(m->d_nfixed, 0, 2 * sizeof(unsigned long long)));
+        HIP_OK(hipMemset(m->d_nfixed, 0, 4 * sizeof(unsigned long long)));
     }
     if ((size_t)n_utts + 1 > m->ws_utts) {
         (void)hipFree(m->d_utt_off);
@@ -2047,6 +2039,12 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
         HIP_OK(hipStreamSynchronize(st)); /* earlier launches may still read the old offsets */
         HIP_OK(hipMemcpy(m->d_utt_off, utt_off, sizeof(int32_t) * ((size_t)n_utts + 1),
                          hipMemcpyHostToDevice));
+        std::vector<uint32_t> starts(((size_t)n_frames + 31) / 32 + 1, 0u);
+        for (int u = 0; u < n_utts; ++u)
+            if (utt_off[u] < n_frames)
+                starts[(size_t)utt_off[u] >> 5] |= 1u << (utt_off[u] & 31);
+        HIP_OK(hipMemcpy(m->d_utt_start, starts.data(), starts.size() * sizeof(uint32_t),
+                         hipMemcpyHostToDevice));
     }
     const ssw_host_model_t *h = m->h;
     ChainParams P;
@@ -2054,6 +2052,9 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
     P.n_utts = n_utts;
     P.n_frames = n_frames;
     P.flags = m->d_flags;
+    P.work = m->d_work;
+    P.work_count = (const unsigned *)(m->d_nfixed + 2);
+    P.utt_start = m->d_utt_start;
     const int64_t pairs = (int64_t)n_frames * m->n_cbf;
     if (m->timing)
         HIP_OK(hipEventRecord(m->ev[0], st));
@@ -2066,14 +2067,15 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
         m->stats[0] = pairs;
         m->stats_pending = 0;
     } else {
-        const int n_words = (int)((pairs + 31) / 32);
-        /* flags are all-zero here: zeroed at allocation, and the senone kernel clears each
+        /* flags are all-zero and the work list is empty here: zeroed at allocation, and the senone kernel clears each
          * frame's words once the fix-up pass has consumed them */
         FramesParams F;
         memset(&F, 0, sizeof(F));
         F.topn_cw = m->d_topn_cw;
         F.topn_sc = m->d_topn_sc;
         F.flags = m->d_flags;
+        F.work = m->d_work;
+        F.work_count = (unsigned *)(m->d_nfixed + 2);
         F.n_frames = n_frames;
         F.n_cbf = m->n_cbf;
         F.n_feat = h->n_feat;
@@ -2098,14 +2100,15 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
             hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 1, false>), grid, dim3(256), 0, st,
                                m->d_rec, d_feats, F);
         HIP_OK(hipGetLastError());
-        int fix_blocks = (n_words + 7) / 8;
-        fix_blocks = fix_blocks > 8192 ? 8192 : fix_blocks;
+        /* one work item per wave; the list is normally far shorter than the grid */
+        int64_t fb = pairs / 64 + 1;
+        const int fix_blocks = (int)(fb > 2048 ? 2048 : fb);
         if (ms)
             hipLaunchKernelGGL((ms_topn_fixup_kernel<13, 2, 4>), dim3(fix_blocks), dim3(64), 0,
-                               st, P, n_words, m->d_nfixed);
+                               st, P, m->d_nfixed);
         else
             hipLaunchKernelGGL((ptm_topn_fixup_kernel<13, 2, 4>), dim3(fix_blocks), dim3(64), 0,
-                               st, P, n_words, m->d_nfixed);
+                               st, P, m->d_nfixed);
         HIP_OK(hipGetLastError());
         m->stats_pending = 1;
     }
