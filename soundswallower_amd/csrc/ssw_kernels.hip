@@ -21,7 +21,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -258,19 +260,14 @@ load_lane_gaussians(const float *rec_cbf, int lane, float (&mean)[NDL][VECLEN],
     }
 }
 
-/* Densities of one frame for the wave's 64*NDL codewords, then one exact top-N step, then the
- * frame's packed result is stored by lane 0. */
+/* Densities of one frame (feature sub-vector x) for the wave's 64*NDL codewords, then one exact
+ * top-N step, then the frame's packed result is stored by lane 0. */
 template <int VECLEN, int NDL, int TOPN>
 __device__ __forceinline__ void
-chain_frame(const ChainParams &P, int t, int cbf, int f, bool do_scan, int lane,
-            const float (&mean)[NDL][VECLEN], const float (&var)[NDL][VECLEN],
-            const float (&det)[NDL], int (&Lc)[TOPN], int (&Ls)[TOPN])
+chain_frame_x(const ChainParams &P, int t, int cbf, const float (&x)[VECLEN], bool do_scan,
+              int lane, const float (&mean)[NDL][VECLEN], const float (&var)[NDL][VECLEN],
+              const float (&det)[NDL], int (&Lc)[TOPN], int (&Ls)[TOPN])
 {
-    const float *xp = P.feats + (size_t)t * P.featdim + P.featoff[f];
-    float x[VECLEN];
-#pragma unroll
-    for (int j = 0; j < VECLEN; ++j)
-        x[j] = xp[j];
     float dv[NDL];
     int iv[NDL];
 #pragma unroll
@@ -288,6 +285,20 @@ chain_frame(const ChainParams &P, int t, int cbf, int f, bool do_scan, int lane,
         static_assert(TOPN == 4, "score store is an int4");
         P.topn_sc[(size_t)t * P.n_cbf + cbf] = make_int4(Ls[0], Ls[1], Ls[2], Ls[3]);
     }
+}
+
+template <int VECLEN, int NDL, int TOPN>
+__device__ __forceinline__ void
+chain_frame(const ChainParams &P, int t, int cbf, int f, bool do_scan, int lane,
+            const float (&mean)[NDL][VECLEN], const float (&var)[NDL][VECLEN],
+            const float (&det)[NDL], int (&Lc)[TOPN], int (&Ls)[TOPN])
+{
+    const float *xp = P.feats + (size_t)t * P.featdim + P.featoff[f];
+    float x[VECLEN];
+#pragma unroll
+    for (int j = 0; j < VECLEN; ++j)
+        x[j] = xp[j];
+    chain_frame_x<VECLEN, NDL, TOPN>(P, t, cbf, x, do_scan, lane, mean, var, det, Lc, Ls);
 }
 
 /* Exact path: one wave per (utterance, cbf) chain, all frames in order, history reset (or
@@ -349,39 +360,38 @@ ptm_topn_fixup_kernel(ChainParams P, unsigned long long *n_fixed)
 {
     const int lane = threadIdx.x;
     float mean[NDL][VECLEN], var[NDL][VECLEN], det[NDL];
-    int loaded_cbf = -1;
     unsigned long long fixed = 0;
     const unsigned n_work = *P.work_count;
     for (unsigned i = blockIdx.x; i < n_work; i += gridDim.x) {
         const uint32_t bit = P.work[i];
         const int t = (int)(bit / (uint32_t)P.n_cbf);
         const int cbf = (int)(bit - (uint32_t)t * (uint32_t)P.n_cbf);
-        const bool at_start = bit_test(P.utt_start, t);
-        if (!at_start && bit_test(P.flags, (long long)bit - P.n_cbf))
-            continue; /* only run heads start a walk */
-        if (cbf != loaded_cbf) {
-            load_lane_gaussians<VECLEN, NDL>(P.rec + (size_t)cbf * (NDL * 64) * SSW_REC_FLOATS,
-                                             lane, mean, var, det);
-            loaded_cbf = cbf;
-        }
-        int Lc[TOPN], Ls[TOPN];
-        if (!at_start) {
-            uint32_t pk = P.topn_cw[(size_t)(t - 1) * P.n_cbf + cbf];
-#pragma unroll
-            for (int k = 0; k < TOPN; ++k)
-                Lc[k] = (pk >> (8 * k)) & 0xff;
-        } else {
-#pragma unroll
-            for (int k = 0; k < TOPN; ++k)
-                Lc[k] = k;
-        }
-#pragma unroll
-        for (int k = 0; k < TOPN; ++k)
-            Ls[k] = INT_MIN;
         const int f = cbf % P.n_feat;
-        for (int tt = t; tt < P.n_frames; ++tt) {
-            if (tt > t
-                && (bit_test(P.utt_start, tt) || !bit_test(P.flags, (long long)tt * P.n_cbf + cbf)))
+        /* everything the item may need is requested at once; the head test comes after */
+        const uint32_t pbit = bit >= (uint32_t)P.n_cbf ? bit - (uint32_t)P.n_cbf : bit;
+        const uint32_t w_start = P.utt_start[t >> 5];
+        const uint32_t w_prev = P.flags[pbit >> 5];
+        const uint32_t pk = P.topn_cw[pbit];
+        const float *xp = P.feats + (size_t)t * P.featdim + P.featoff[f];
+        float x[VECLEN];
+#pragma unroll
+        for (int j = 0; j < VECLEN; ++j)
+            x[j] = xp[j];
+        load_lane_gaussians<VECLEN, NDL>(P.rec + (size_t)cbf * (NDL * 64) * SSW_REC_FLOATS, lane,
+                                         mean, var, det);
+        const bool at_start = (w_start >> (t & 31)) & 1u;
+        if (!at_start && ((w_prev >> (pbit & 31)) & 1u))
+            continue; /* only run heads start a walk */
+        int Lc[TOPN], Ls[TOPN];
+#pragma unroll
+        for (int k = 0; k < TOPN; ++k) {
+            Lc[k] = at_start ? k : (int)((pk >> (8 * k)) & 0xff);
+            Ls[k] = INT_MIN;
+        }
+        chain_frame_x<VECLEN, NDL, TOPN>(P, t, cbf, x, true, lane, mean, var, det, Lc, Ls);
+        ++fixed;
+        for (int tt = t + 1; tt < P.n_frames; ++tt) {
+            if (bit_test(P.utt_start, tt) || !bit_test(P.flags, (long long)tt * P.n_cbf + cbf))
                 break;
             chain_frame<VECLEN, NDL, TOPN>(P, tt, cbf, f, true, lane, mean, var, det, Lc, Ls);
             ++fixed;
@@ -421,7 +431,7 @@ struct FramesParams {
     uint32_t *flags;
     uint32_t *work;       /* flagged pairs, appended as found; entry = t*n_cbf + cbf */
     unsigned *work_count;
-    int n_frames, n_cbf, n_feat, featdim;
+    int n_frames, n_cbf, n_feat, featdim, tile_groups;
     int featoff[SSW_MAX_FEAT];
 };
 
@@ -431,23 +441,61 @@ med3f(float a, float b, float c)
     return __builtin_amdgcn_fmed3f(a, b, c);
 }
 
+#ifdef SSW_TIMELINE
+__device__ unsigned long long g_timeline[8192 * 6];
+#define SSW_TL(k)                                                                            \
+    if (lane == 0) {                                                                         \
+        int wv = blockIdx.x * 4 + (threadIdx.x >> 6);                                        \
+        if (wv < 8192)                                                                       \
+            g_timeline[wv * 6 + (k)] = __builtin_amdgcn_s_memtime();                        \
+    }
+#else
+#define SSW_TL(k)
+#endif
+
 template <int VECLEN, int FPL, bool MS>
 __global__ void __launch_bounds__(256)
-ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ feats,
+ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ recq,
+                       const float *__restrict__ recmax, const float *__restrict__ feats,
                        FramesParams P)
 {
     static_assert(FPL == 1 || FPL == 2, "one or two frames per lane");
     const int lane = threadIdx.x & 63;
-    const int cbf = blockIdx.y;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    /* Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one).  The (codebook,
+     * stream) x tile-group pairs are cut into 8 contiguous chunks, one per XCD, so that the
+     * workgroups that stream the same 16 KB of records sit behind the same L2. */
+    const int n_pairs = P.n_cbf * P.tile_groups;
+    const int chunk = (n_pairs + 7) >> 3;
+    const int pair = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || pair >= n_pairs)
+        return;
+    const int cbf = pair / P.tile_groups;
+    const int tile = (pair - cbf * P.tile_groups) * 4 + (threadIdx.x >> 6);
     const int t_base = tile * 64 * FPL;
     if (t_base >= P.n_frames)
         return;
+    SSW_TL(0)
+#ifdef SSW_TIMELINE
+    if (lane == 0) {
+        int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (wv < 8192) {
+            g_timeline[wv * 6 + 4] = __builtin_amdgcn_s_getreg(63492); /* HW_ID */
+            g_timeline[wv * 6 + 5] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); /* XCC_ID */
+        }
+    }
+#endif
     const int f = cbf % P.n_feat;
     const float *rec_cbf = rec + (size_t)cbf * 128 * SSW_REC_FLOATS;
+    const float *rq_cbf = recq + (size_t)cbf * 128 * SSW_REC_FLOATS;
+    const float d0 = recmax[(size_t)cbf * SSW_REC_FLOATS]; /* the keys are relative to this */
+    /* touch every 128-byte line of this codebook's two record tables now, so that the scalar
+     * loads of the scan and the gathers after it find them in L2 */
+    float touch = rq_cbf[lane * SSW_REC_FLOATS] + rq_cbf[(64 + lane) * SSW_REC_FLOATS]
+        + rec_cbf[lane * SSW_REC_FLOATS] + rec_cbf[(64 + lane) * SSW_REC_FLOATS];
 
     int tt[FPL];
     float x[FPL][VECLEN];
+    float2v xv[VECLEN], xq[VECLEN]; /* x and x*x of the lane's frames, packed per dimension */
 #pragma unroll
     for (int h = 0; h < FPL; ++h) {
         tt[h] = t_base + h * 64 + lane;
@@ -456,6 +504,12 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
 #pragma unroll
         for (int j = 0; j < VECLEN; ++j)
             x[h][j] = xp[j];
+    }
+#pragma unroll
+    for (int j = 0; j < VECLEN; ++j) {
+        xv[j].x = x[0][j];
+        xv[j].y = x[FPL - 1][j];
+        xq[j] = xv[j] * xv[j];
     }
 
     const float NEG_INF = -__builtin_huge_valf(), POS_INF = __builtin_huge_valf();
@@ -477,7 +531,7 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
     v16f a_lo, a_hi, b_lo, b_hi;
     asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40"
                  : "=&s"(a_lo), "=&s"(a_hi)
-                 : "s"(rec_cbf));
+                 : "s"(rq_cbf));
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a_lo), "+s"(a_hi));
 
 #define SSW_REC_ISSUE(lo, hi, ptr, tie)                                                      \
@@ -488,17 +542,29 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
 #define SSW_REC_SCAN(lo, hi, cwv)                                                            \
     {                                                                                        \
         float d[FPL];                                                                        \
-        if (FPL == 2) {                                                                      \
+        if (__float_as_uint(hi[SSW_REC_FLOATS - 1 - SSW_REC_VAR]) != 0u) {                   \
+            /* ill-conditioned density (wave-uniform test): the record holds mean/det/scale  \
+             * and the value is formed the reference's way */                                \
             float2v dd = { lo[SSW_REC_DET], lo[SSW_REC_DET] };                               \
             _Pragma("unroll") for (int j = 0; j < VECLEN; ++j)                               \
             {                                                                                \
-                float2v xx = { x[0][j], x[FPL - 1][j] };                                     \
                 float2v mm = { lo[j], lo[j] };                                               \
                 float2v vv = { hi[j], hi[j] };                                               \
-                float2v diff = xx - mm;                                                      \
+                float2v diff = xv[j] - mm;                                                   \
                 float2v sq = diff * diff;                                                    \
                 float2v c = sq * vv;                                                         \
                 dd = dd - c;                                                                 \
+            }                                                                                \
+            d[0] = dd.x - d0;                                                                \
+            d[FPL - 1] = dd.y - d0;                                                          \
+        } else if (FPL == 2) {                                                               \
+            float2v dd = { lo[SSW_REC_DET], lo[SSW_REC_DET] };                               \
+            _Pragma("unroll") for (int j = 0; j < VECLEN; ++j)                               \
+            {                                                                                \
+                float2v aa = { lo[j], lo[j] };                                               \
+                float2v bb = { hi[j], hi[j] };                                               \
+                dd = __builtin_elementwise_fma(aa, xv[j], dd);                               \
+                dd = __builtin_elementwise_fma(bb, xq[j], dd);                               \
             }                                                                                \
             d[0] = dd.x;                                                                     \
             d[FPL - 1] = dd.y;                                                               \
@@ -506,10 +572,8 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
             float dd = lo[SSW_REC_DET];                                                      \
             _Pragma("unroll") for (int j = 0; j < VECLEN; ++j)                               \
             {                                                                                \
-                float diff = x[0][j] - lo[j];                                                \
-                float sq = diff * diff;                                                      \
-                float c = sq * hi[j];                                                        \
-                dd = dd - c;                                                                 \
+                dd = __builtin_fmaf(lo[j], xv[j].x, dd);                                     \
+                dd = __builtin_fmaf(hi[j], xq[j].x, dd);                                     \
             }                                                                                \
             d[0] = dd;                                                                       \
         }                                                                                    \
@@ -525,12 +589,13 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
     }
 
     static_assert(SSW_REC_VAR == 16 && SSW_REC_FLOATS == 32, "record = two 16-dword halves");
+    SSW_TL(1)
     for (int cw = 0; cw < 128; cw += 2) {
-        const float *rb = rec_cbf + (cw + 1) * SSW_REC_FLOATS;
+        const float *rb = rq_cbf + (cw + 1) * SSW_REC_FLOATS;
         SSW_REC_ISSUE(b_lo, b_hi, rb, a_lo);
         SSW_REC_SCAN(a_lo, a_hi, cw);
         SSW_REC_WAIT(b_lo, b_hi, L[FPL - 1][0]);
-        const float *ra = rec_cbf + (cw + 2 < 128 ? cw + 2 : 127) * SSW_REC_FLOATS;
+        const float *ra = rq_cbf + (cw + 2 < 128 ? cw + 2 : 127) * SSW_REC_FLOATS;
         SSW_REC_ISSUE(a_lo, a_hi, ra, b_lo);
         SSW_REC_SCAN(b_lo, b_hi, cw + 1);
         SSW_REC_WAIT(a_lo, a_hi, L[FPL - 1][0]);
@@ -538,6 +603,8 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
 #undef SSW_REC_ISSUE
 #undef SSW_REC_WAIT
 #undef SSW_REC_SCAN
+    SSW_TL(2)
+    asm volatile("" ::"v"(touch));
 
 #pragma unroll
     for (int h = 0; h < FPL; ++h) {
@@ -588,11 +655,18 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
          * its 7 borrowed bits pushed towards +inf */
         uint32_t kb = __float_as_uint(L[h][4]);
         float ub = __uint_as_float((kb & 0x80000000u) ? (kb & ~127u) : (kb | 127u));
+        /* the scan's keys are upper bounds, relative to d0, up to a term proportional to
+         * their own size: v + 104 * 2^-24 |v| is increasing in v, so the
+         * 5th key bounds every density outside the four; back to absolute, rounded up */
+        ub = ub + __builtin_fabsf(ub) * 6.198883056640625e-06f;
+        ub = ub + d0;
+        ub = ub + __builtin_fabsf(ub) * 2.384185791015625e-07f;
         bool proven;
         if (MS) /* compute_dist orders by float; exact ties are what needs the exact pass */
             proven = dv[0] > dv[1] && dv[1] > dv[2] && dv[2] > dv[3] && dv[3] > ub;
         else
-            proven = s[0] > s[1] && s[1] > s[2] && s[2] > s[3] && s[3] > dens2int(ub);
+            proven = s[0] > s[1] && s[1] > s[2] && s[2] > s[3] && ub == ub
+                && s[3] > dens2int(ub);
         if (tt[h] < P.n_frames) {
             size_t idx = (size_t)tt[h] * P.n_cbf + cbf;
             P.topn_cw[idx] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16)
@@ -604,6 +678,7 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
             }
         }
     }
+    SSW_TL(3)
 }
 
 /* Exact pass of the ms scorer for flagged pairs: compute_dist (src/ms_gauden.c:384-432) is
@@ -1547,6 +1622,9 @@ struct ssw_model_s {
     int device;
     int n_cbf, sen_stride;
     float *d_rec;
+    float *d_recq;   /* the same densities as a quadratic form in x (the speculative scan) */
+    float *d_recmax; /* [n_cbf][SSW_REC_FLOATS] per-(codebook, stream) constants of the scan: [0] = d0 */
+    int n_exact_form; /* densities the scan evaluates the reference's way */
     uint8_t *d_mixw, *d_ms_pdf, *d_sen2cb, *d_logadd8, *d_tp, *d_quad_cb;
     short4 *d_slot_sen;
     int n_quads, slot_stride;
@@ -1605,6 +1683,65 @@ upload_model(ssw_model_s *m)
     if (dev_alloc(&m->d_rec, rec.size()) < 0)
         return -1;
     HIP_OK(hipMemcpy(m->d_rec, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice));
+    {
+        /* The speculative scan evaluates  det - sum var (x - mean)^2  as a quadratic form in x,
+         *   key = c + sum_j (a_j x_j + b_j x_j^2),  a = 2 var mean,  b = -var,
+         *   c = (det - d0) - R + bias,  R = sum var mean^2,  d0 = the codebook's median det,
+         * with 26 fused multiply-adds.  With u = 2^-24, S = sum var (x - mean)^2 and
+         * M = |det - d0| + R + sum |a x| + sum |b| x^2 <= |det - d0| + 6 R + 3 S
+         * (Cauchy-Schwarz), the form is within 27 u M of the real number and the reference's
+         * fp32 value within 13 u |det| + 16 u S of it; with S <= |det - d0| + |value - d0| that
+         * is u (124 |det - d0| + 162 R + 13 |det|) -- folded into c as `bias`, so the key is an
+         * upper bound -- plus 97 u |value - d0|, which the kernel adds to the one key it uses as
+         * a bound.  Densities whose bias would exceed 4 score units (floored variances far from
+         * the origin) keep mean/det/scale in their record and are evaluated the reference's
+         * way; a non-zero last float marks them. */
+        std::vector<float> rq(rec.size(), 0.0f), rmax((size_t)ncbf * SSW_REC_FLOATS, 0.0f);
+        const double u24 = 1.0 / 16777216.0;
+        int n_exact_form = 0;
+        for (int cbf = 0; cbf < ncbf; ++cbf) {
+            std::vector<float> dets((size_t)h->n_density);
+            for (int d = 0; d < h->n_density; ++d)
+                dets[d] = rec[((size_t)cbf * h->n_density + d) * SSW_REC_FLOATS + SSW_REC_DET];
+            std::nth_element(dets.begin(), dets.begin() + dets.size() / 2, dets.end());
+            const float d0 = dets[dets.size() / 2];
+            rmax[(size_t)cbf * SSW_REC_FLOATS] = d0;
+            for (int d = 0; d < h->n_density; ++d) {
+                const float *r = rec.data() + ((size_t)cbf * h->n_density + d) * SSW_REC_FLOATS;
+                float *q = rq.data() + ((size_t)cbf * h->n_density + d) * SSW_REC_FLOATS;
+                const double det = r[SSW_REC_DET], delta = det - (double)d0;
+                double R = 0.0;
+                bool finite = std::isfinite(det);
+                for (int j = 0; j < SSW_MAX_VECLEN; ++j) {
+                    double mean = r[j], var = r[SSW_REC_VAR + j];
+                    R += fabs(var) * mean * mean;
+                    finite = finite && std::isfinite(mean) && std::isfinite(var) && var >= 0.0;
+                }
+                const double bias = 1.05 * u24 * (124.0 * fabs(delta) + 162.0 * R + 13.0 * fabs(det));
+                if (!finite || !(bias <= 4.0)) {
+                    memcpy(q, r, sizeof(float) * SSW_REC_FLOATS);
+                    q[SSW_REC_FLOATS - 1] = 1.0f;
+                    ++n_exact_form;
+                    continue;
+                }
+                for (int j = 0; j < SSW_MAX_VECLEN; ++j) {
+                    q[j] = (float)(2.0 * (double)r[SSW_REC_VAR + j] * (double)r[j]);
+                    q[SSW_REC_VAR + j] = -r[SSW_REC_VAR + j];
+                }
+                const double c = delta - R + bias;
+                float cf = (float)c;
+                if ((double)cf < c)
+                    cf = nextafterf(cf, INFINITY);
+                q[SSW_REC_DET] = cf;
+            }
+        }
+        m->n_exact_form = n_exact_form;
+        if (dev_alloc(&m->d_recq, rq.size()) < 0 || dev_alloc(&m->d_recmax, rmax.size()) < 0)
+            return -1;
+        HIP_OK(hipMemcpy(m->d_recq, rq.data(), rq.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(m->d_recmax, rmax.data(), rmax.size() * sizeof(float),
+                         hipMemcpyHostToDevice));
+    }
     HIP_OK(hipMalloc((void **)&m->d_logadd8, 256));
     HIP_OK(hipMemcpy(m->d_logadd8, h->logadd8, 256, hipMemcpyHostToDevice));
     if (h->n_sen) {
@@ -1732,6 +1869,8 @@ ssw_model_free(ssw_model_t *m)
         return;
     }
     (void)hipFree(m->d_rec);
+    (void)hipFree(m->d_recq);
+    (void)hipFree(m->d_recmax);
     (void)hipFree(m->d_mixw);
     (void)hipFree(m->d_ms_pdf);
     (void)hipFree(m->d_sen2cb);
@@ -2086,23 +2225,26 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
         const bool two = (int64_t)((n_frames + 127) / 128) * m->n_cbf >= 2048;
         const int fpl = two ? 2 : 1;
         const int tiles = (n_frames + 64 * fpl - 1) / (64 * fpl);
-        dim3 grid((tiles + 3) / 4, m->n_cbf);
+        F.tile_groups = (tiles + 3) / 4;
+        dim3 grid((unsigned)((((int64_t)F.tile_groups * m->n_cbf + 7) / 8) * 8));
         if (two && ms)
             hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 2, true>), grid, dim3(256), 0, st,
-                               m->d_rec, d_feats, F);
+                               m->d_rec, m->d_recq, m->d_recmax, d_feats, F);
         else if (two)
             hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 2, false>), grid, dim3(256), 0, st,
-                               m->d_rec, d_feats, F);
+                               m->d_rec, m->d_recq, m->d_recmax, d_feats, F);
         else if (ms)
             hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 1, true>), grid, dim3(256), 0, st,
-                               m->d_rec, d_feats, F);
+                               m->d_rec, m->d_recq, m->d_recmax, d_feats, F);
         else
             hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 1, false>), grid, dim3(256), 0, st,
-                               m->d_rec, d_feats, F);
+                               m->d_rec, m->d_recq, m->d_recmax, d_feats, F);
         HIP_OK(hipGetLastError());
         /* one work item per wave; the list is normally far shorter than the grid */
         int64_t fb = pairs / 64 + 1;
-        const int fix_blocks = (int)(fb > 2048 ? 2048 : fb);
+        int fix_blocks = (int)(fb > 2048 ? 2048 : fb);
+        if (getenv("SSW_FIX_BLOCKS"))
+            fix_blocks = atoi(getenv("SSW_FIX_BLOCKS"));
         if (ms)
             hipLaunchKernelGGL((ms_topn_fixup_kernel<13, 2, 4>), dim3(fix_blocks), dim3(64), 0,
                                st, P, m->d_nfixed);
@@ -2119,6 +2261,18 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
         return -1;
     if (m->timing)
         HIP_OK(hipEventRecord(m->ev[2], st));
+#ifdef SSW_TIMELINE
+    if (getenv("SSW_TIMELINE_OUT")) {
+        std::vector<unsigned long long> tl(8192 * 6);
+        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_timeline), tl.size() * 8));
+        FILE *fp = fopen(getenv("SSW_TIMELINE_OUT"), "wb");
+        if (fp) {
+            fwrite(tl.data(), 8, tl.size(), fp);
+            fclose(fp);
+        }
+    }
+#endif
     m->last_n_frames = n_frames;
     m->stats[1] = pairs;
     return 0;

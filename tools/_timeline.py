@@ -1,0 +1,37 @@
+import os, sys, shutil, numpy as np
+root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+shutil.copy(os.path.join(root, "gpurun_tl/libssw_amd.so"), os.path.join(root, "soundswallower_amd/libssw_amd.so"))
+os.environ["SSW_TIMELINE_OUT"] = "/tmp/tl.bin"
+sys.path.insert(0, root)
+import torch
+from soundswallower_amd import api, synth
+m = api.Model(api.model_dir("en-us"))
+raw = synth.read_raw_means(api.model_dir("en-us"))
+feats = np.concatenate([synth.synth_features(raw, 256, 12345 + u) for u in range(16)])
+off = np.arange(17, dtype=np.int32) * 256
+for i in range(5):
+    out = m.score_batch_host(feats, off) if hasattr(m, "score_batch_host") else m.score_batch(feats, off)
+tl = np.fromfile("/tmp/tl.bin", dtype=np.uint64).reshape(-1, 6)
+tl = tl[tl[:, 0] != 0]
+xcc_all = tl[:, 5].astype(np.int64) & 0xf
+hw_all = tl[:, 4].astype(np.int64)
+grp = xcc_all * 100000 + ((hw_all >> 13) & 7) * 1000 + ((hw_all >> 8) & 15)
+T = tl[:, :4].astype(np.int64)
+for x in np.unique(grp):
+    T[grp == x] -= T[grp == x, 0].min()
+print("waves", len(tl), "clock units (s_memtime)")
+for k, nm in enumerate(("start", "loop begin", "loop end", "end")):
+    print(f"{nm:11s} min {T[:,k].min():8d} p50 {int(np.median(T[:,k])):8d} p90 {int(np.percentile(T[:,k],90)):8d} max {T[:,k].max():8d}")
+print("loop duration p10/p50/p90/max", np.percentile(T[:,2]-T[:,1],[10,50,90,100]).astype(int))
+print("prologue p50/max", np.percentile(T[:,1]-T[:,0],[50,100]).astype(int), "epilogue p50/max", np.percentile(T[:,3]-T[:,2],[50,100]).astype(int))
+hw = tl[:, 4].astype(np.int64); xcc = tl[:, 5].astype(np.int64) & 0xf
+simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; se = (hw >> 13) & 7
+key = xcc * 100000 + se * 1000 + cu * 10 + simd
+u, c = np.unique(key, return_counts=True)
+print("distinct (xcc,se,cu,simd):", len(u), "waves per SIMD histogram:", np.bincount(c))
+cukey = xcc * 1000 + se * 100 + cu
+u2, c2 = np.unique(cukey, return_counts=True)
+print("distinct CUs:", len(u2), "waves per CU histogram:", np.bincount(c2))
+late = T[:, 0] > 20000
+print("waves starting late (>20000):", late.sum())
+print("per-xcc end max:", [int(T[xcc_all == x, 3].max()) for x in np.unique(xcc_all)])
