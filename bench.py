@@ -30,7 +30,9 @@ sys.path.insert(0, ROOT)
 N_UTTS = 16
 UTT_FRAMES = 256
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, MI355X_MICROARCH.md
-VALU_PEAK_OPS = 78.6e12        # non-fused fp32 lane-ops/s: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+N_SIMD = 1024                   # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9
+PMC_FILE = "r01_g_pmc.json"    # committed rocprofv3 --pmc measurement of this exact step
 
 
 def algorithmic_bytes(n_sen, n_feat, topn, n_cb, n_density, veclen_total, batch):
@@ -71,6 +73,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--model", default="en-us")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--utts", type=int, default=N_UTTS,
+                    help="utterances (x256 frames) per GPU per step; the default is BASELINE.json "
+                         "configs[1], 4096 frames")
     args = ap.parse_args()
 
     import torch
@@ -101,7 +106,7 @@ def main():
     means = raw_means(mdir)
 
     # this rank's shard of the global utterance list (weak scaling: N_UTTS per rank)
-    global_utts = list(range(N_UTTS * world))
+    global_utts = list(range(args.utts * world))
     mine = shard_utterances([UTT_FRAMES] * len(global_utts), world)[rank]
     feats = np.concatenate([ssw.synth_features(means, UTT_FRAMES, 12345 + u) for u in mine])
     utt_off = (np.arange(len(mine) + 1) * UTT_FRAMES).astype(np.int32)
@@ -153,17 +158,18 @@ def main():
     names = ("topn_kernel", "senone_kernel")
     total_frames = n_frames * world * args.steps
     fps = total_frames / elapsed
-    ops_per_frame = model.n_cb * model.n_feat * (model.n_density + model.topn) * 13 * 4
     flagged, pairs = model.last_stats()
     # roofline of the hot path = the launches of one step (top-N pass incl. its exact fix-up,
     # senone pass); algorithmic bytes = SURVEY 8(d)'s 72,345 B/frame x frames per launch set
     path_ms = float(k_ms.sum())
     achieved = ab["path"] * n_frames / (path_ms * 1e-3) / 1e9
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")
+    traffic = valu_instr = None
+    tfile = os.path.join(ROOT, "profiles", PMC_FILE)
     if os.path.exists(tfile) and n_frames == 4096 and args.model == "en-us":
         with open(tfile) as fh:      # PMC counters cannot be read from inside this process;
-            traffic = json.load(fh)["hbm_bytes"]  # committed rocprofv3 measurement of this step
+            pmc = json.load(fh)      # committed rocprofv3 measurement of this step
+        traffic = pmc["hbm_bytes"]
+        valu_instr = pmc["valu_wave_instr_per_step"]
     per_kernel = {
         nm: {"ms": float(k_ms[i]), "algorithmic_bytes_per_frame": ab[nm],
              "achieved_GBps": ab[nm] * n_frames / (k_ms[i] * 1e-3) / 1e9,
@@ -182,7 +188,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f32+i32",
         "data": "synthetic",
-        "config": {"workload": f"PTM senone scoring, {args.model}, {N_UTTS} utterances x "
+        "config": {"workload": f"PTM senone scoring, {args.model}, {args.utts} utterances x "
                                f"{UTT_FRAMES} frames = {n_frames} frames per GPU per step, "
                                f"39-dim features resident in HBM, compallsen=yes, topn=4",
                    "n_sen": model.n_sen, "n_cb": model.n_cb, "parallelism": f"utt-shard x{world}"},
@@ -192,7 +198,11 @@ def main():
                      "kernel_ms": path_ms, "algorithmic_bytes_per_frame": ab["path"],
                      "note": "VALU-issue bound, not HBM bound (DESIGN.md section 5): see valu_frac"},
         "kernels": per_kernel,
-        "valu_frac": fps / world * ops_per_frame / VALU_PEAK_OPS,
+        # share of the VALU issue slots the step uses if every wave64 instruction took the
+        # nominal 4 cycles (SQ_INSTS_VALU from the PMC file); add/sub/mul/fma/logic issue in 2 on
+        # gfx950 (tools/microbench/valu_rate.hip), so this over-counts the senone kernel
+        "valu_frac": (valu_instr * 4.0 / N_SIMD / CLOCK_HZ / (path_ms * 1e-3)
+                      if valu_instr else None),
         "exact_pass_share": flagged / max(pairs, 1),
     }
     if not args.no_cpu_baseline:

@@ -1257,7 +1257,12 @@ orc_ptm_frame_eval(orc_model_t *m, int16_t *senscr, const uint8_t *senone_active
                         d = mly - fden;
                         r = fden;
                     }
-                    fden = r - ((const uint8_t *)m->lmath_8b->table)[d];
+                    /* the reference indexes its (>= 256-entry, :107-109) table without a bound;
+                     * d can only pass 255 when fden has gone negative, where the reference reads
+                     * past its allocation.  The restatement defines that read as 0, the value
+                     * every entry from 29 up holds. */
+                    fden = r - ((size_t)d < m->lmath_8b->table_size
+                                    ? ((const uint8_t *)m->lmath_8b->table)[d] : 0);
                 }
             }
             ascore += fden;

@@ -423,6 +423,7 @@ ptm_topn_fixup_kernel(ChainParams P, unsigned long long *n_fixed)
  *     sequential state machine.
  */
 typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4))); /* 4-byte aligned float4 */
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 struct FramesParams {
@@ -441,6 +442,8 @@ med3f(float a, float b, float c)
     return __builtin_amdgcn_fmed3f(a, b, c);
 }
 
+#define SSW_EXLIST_STRIDE 132 /* [0] count, [1..] codewords the scan leaves to the exact form */
+
 #ifdef SSW_TIMELINE
 __device__ unsigned long long g_timeline[8192 * 6];
 #define SSW_TL(k)                                                                            \
@@ -456,8 +459,8 @@ __device__ unsigned long long g_timeline[8192 * 6];
 template <int VECLEN, int FPL, bool MS>
 __global__ void __launch_bounds__(256)
 ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ recq,
-                       const float *__restrict__ recmax, const float *__restrict__ feats,
-                       FramesParams P)
+                       const float *__restrict__ recmax, const uint32_t *__restrict__ exlist,
+                       const float *__restrict__ feats, FramesParams P)
 {
     static_assert(FPL == 1 || FPL == 2, "one or two frames per lane");
     const int lane = threadIdx.x & 63;
@@ -501,8 +504,18 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
         tt[h] = t_base + h * 64 + lane;
         int tl = tt[h] < P.n_frames ? tt[h] : P.n_frames - 1;
         const float *xp = feats + (size_t)tl * P.featdim + P.featoff[f];
+        /* every lane reads its own row: 16-byte loads (rows are only 4-byte aligned, which
+         * global loads allow) cut the number of line look-ups per wave by three */
 #pragma unroll
-        for (int j = 0; j < VECLEN; ++j)
+        for (int j = 0; j + 4 <= VECLEN; j += 4) {
+            float4u v = *reinterpret_cast<const float4u *>(xp + j);
+            x[h][j] = v.x;
+            x[h][j + 1] = v.y;
+            x[h][j + 2] = v.z;
+            x[h][j + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = VECLEN & ~3; j < VECLEN; ++j)
             x[h][j] = xp[j];
     }
 #pragma unroll
@@ -539,25 +552,20 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
                  : "=&s"(lo), "=&s"(hi), "+s"(tie)                                           \
                  : "s"(ptr))
 #define SSW_REC_WAIT(lo, hi, vtie) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lo), "+s"(hi), "+v"(vtie))
+#define SSW_KEY_INSERT(d, cwv)                                                               \
+    _Pragma("unroll") for (int h = 0; h < FPL; ++h)                                          \
+    {                                                                                        \
+        float key = __uint_as_float((__float_as_uint(d[h]) & keymask) | (uint32_t)(cwv));    \
+        L[h][4] = med3f(L[h][3], L[h][4], key);                                              \
+        L[h][3] = med3f(L[h][2], L[h][3], key);                                              \
+        L[h][2] = med3f(L[h][1], L[h][2], key);                                              \
+        L[h][1] = med3f(L[h][0], L[h][1], key);                                              \
+        asm("v_max_f32 %0, %1, %2" : "=v"(L[h][0]) : "v"(L[h][0]), "v"(key));               \
+    }
 #define SSW_REC_SCAN(lo, hi, cwv)                                                            \
     {                                                                                        \
         float d[FPL];                                                                        \
-        if (__float_as_uint(hi[SSW_REC_FLOATS - 1 - SSW_REC_VAR]) != 0u) {                   \
-            /* ill-conditioned density (wave-uniform test): the record holds mean/det/scale  \
-             * and the value is formed the reference's way */                                \
-            float2v dd = { lo[SSW_REC_DET], lo[SSW_REC_DET] };                               \
-            _Pragma("unroll") for (int j = 0; j < VECLEN; ++j)                               \
-            {                                                                                \
-                float2v mm = { lo[j], lo[j] };                                               \
-                float2v vv = { hi[j], hi[j] };                                               \
-                float2v diff = xv[j] - mm;                                                   \
-                float2v sq = diff * diff;                                                    \
-                float2v c = sq * vv;                                                         \
-                dd = dd - c;                                                                 \
-            }                                                                                \
-            d[0] = dd.x - d0;                                                                \
-            d[FPL - 1] = dd.y - d0;                                                          \
-        } else if (FPL == 2) {                                                               \
+        if (FPL == 2) {                                                                      \
             float2v dd = { lo[SSW_REC_DET], lo[SSW_REC_DET] };                               \
             _Pragma("unroll") for (int j = 0; j < VECLEN; ++j)                               \
             {                                                                                \
@@ -577,15 +585,7 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
             }                                                                                \
             d[0] = dd;                                                                       \
         }                                                                                    \
-        _Pragma("unroll") for (int h = 0; h < FPL; ++h)                                      \
-        {                                                                                    \
-            float key = __uint_as_float((__float_as_uint(d[h]) & keymask) | (uint32_t)(cwv)); \
-            L[h][4] = med3f(L[h][3], L[h][4], key);                                          \
-            L[h][3] = med3f(L[h][2], L[h][3], key);                                          \
-            L[h][2] = med3f(L[h][1], L[h][2], key);                                          \
-            L[h][1] = med3f(L[h][0], L[h][1], key);                                          \
-            asm("v_max_f32 %0, %1, %2" : "=v"(L[h][0]) : "v"(L[h][0]), "v"(key));           \
-        }                                                                                    \
+        SSW_KEY_INSERT(d, cwv)                                                               \
     }
 
     static_assert(SSW_REC_VAR == 16 && SSW_REC_FLOATS == 32, "record = two 16-dword halves");
@@ -603,6 +603,31 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
 #undef SSW_REC_ISSUE
 #undef SSW_REC_WAIT
 #undef SSW_REC_SCAN
+    /* The few ill-conditioned densities of this codebook (their scan records are inert: key
+     * -3e38) are evaluated the reference's way from the exact records; their keys need no bias. */
+    {
+        const uint32_t *xl = exlist + (size_t)cbf * SSW_EXLIST_STRIDE;
+        const int n_ex = (int)xl[0];
+        for (int i = 0; i < n_ex; ++i) {
+            const int cwx = (int)xl[1 + i];
+            const float *r = rec_cbf + cwx * SSW_REC_FLOATS;
+            float2v dd = { r[SSW_REC_DET], r[SSW_REC_DET] };
+#pragma unroll
+            for (int j = 0; j < VECLEN; ++j) {
+                float2v mm = { r[j], r[j] };
+                float2v vv = { r[SSW_REC_VAR + j], r[SSW_REC_VAR + j] };
+                float2v diff = xv[j] - mm;
+                float2v sq = diff * diff;
+                float2v c = sq * vv;
+                dd = dd - c;
+            }
+            float d[FPL];
+            d[0] = dd.x - d0;
+            d[FPL - 1] = dd.y - d0;
+            SSW_KEY_INSERT(d, cwx)
+        }
+    }
+#undef SSW_KEY_INSERT
     SSW_TL(2)
     asm volatile("" ::"v"(touch));
 
@@ -805,6 +830,8 @@ struct SenoneParams {
 
 constexpr int SEN_MAX_THREADS = 1024;
 
+#define SSW_LOGADD_LDS 512 /* 8-bit log-add table in LDS: 256 entries + zero padding */
+
 /* fast_logmath_add (tied_mgau_common.h:100-117): min(x, y) - table[|x - y|] */
 __device__ __forceinline__ int
 fast_logadd(int x, int y, const uint8_t *tab)
@@ -829,10 +856,13 @@ ptm_senone_kernel(SenoneParams P)
     static_assert(TOPN == 4, "top-N block is packed 4 x 8 bit");
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_cbf = P.n_cb * P.n_feat;
-    /* LDS carve: logadd[256] | norm[FPB][8] | ns4[FPB][n_cbf] | cw4[FPB][n_cbf] | red[FPB][16] */
+    /* LDS carve: logadd[512] | norm[FPB][8] | ns4[FPB][n_cbf] | cw4[FPB][n_cbf] | red[FPB][16].
+     * The table is indexed by |x - y| without a bound, as in the reference; x, y <= 255 + 96 and
+     * the running value can dip below zero, so it is padded with zeros to 512 entries. */
     uint8_t *s_tab = smem;
-    int *s_norm = reinterpret_cast<int *>(smem + 256);
-    uint32_t *s_ns4 = reinterpret_cast<uint32_t *>(smem + 256 + 4 * SSW_MAX_FEAT * FPB);
+    int *s_norm = reinterpret_cast<int *>(smem + SSW_LOGADD_LDS);
+    uint32_t *s_ns4
+        = reinterpret_cast<uint32_t *>(smem + SSW_LOGADD_LDS + 4 * SSW_MAX_FEAT * FPB);
     uint32_t *s_cw4 = s_ns4 + FPB * n_cbf;
     int *s_red = reinterpret_cast<int *>(s_cw4 + FPB * n_cbf);
     /* byte offsets of the 4 mixture-weight rows of every (frame, codebook, stream) */
@@ -844,8 +874,8 @@ ptm_senone_kernel(SenoneParams P)
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
 
-    if (tid < 256)
-        s_tab[tid] = P.logadd8[tid];
+    for (int i = tid; i < SSW_LOGADD_LDS; i += nthr)
+        s_tab[i] = i < 256 ? P.logadd8[i] : (uint8_t)0;
     if (tid < SSW_MAX_FEAT * FPB)
         s_norm[tid] = SSW_WORST_SCORE;
     if (P.flags != nullptr) { /* these frames' flag bits have been consumed by the fix-up pass */
@@ -1042,7 +1072,7 @@ struct SenoneFrameParams {
 __global__ void __launch_bounds__(1024)
 ptm_senone_frame_kernel(SenoneFrameParams P)
 {
-    __shared__ uint8_t s_tab[256];
+    __shared__ uint8_t s_tab[SSW_LOGADD_LDS];
     __shared__ int s_norm[SSW_MAX_FEAT];
     __shared__ int s_red[16];
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1051,8 +1081,8 @@ ptm_senone_frame_kernel(SenoneFrameParams P)
     uint32_t *s_cw4 = s_ns4 + n_cbf;
     const int tid = threadIdx.x, nthr = blockDim.x;
 
-    if (tid < 256)
-        s_tab[tid] = P.logadd8[tid];
+    for (int i = tid; i < SSW_LOGADD_LDS; i += nthr)
+        s_tab[i] = i < 256 ? P.logadd8[i] : (uint8_t)0;
     if (tid < SSW_MAX_FEAT)
         s_norm[tid] = SSW_WORST_SCORE;
     __syncthreads();
@@ -1624,7 +1654,8 @@ struct ssw_model_s {
     float *d_rec;
     float *d_recq;   /* the same densities as a quadratic form in x (the speculative scan) */
     float *d_recmax; /* [n_cbf][SSW_REC_FLOATS] per-(codebook, stream) constants of the scan: [0] = d0 */
-    int n_exact_form; /* densities the scan evaluates the reference's way */
+    uint32_t *d_exlist; /* [n_cbf][SSW_EXLIST_STRIDE] densities the scan leaves to the exact form */
+    int n_exact_form;
     uint8_t *d_mixw, *d_ms_pdf, *d_sen2cb, *d_logadd8, *d_tp, *d_quad_cb;
     short4 *d_slot_sen;
     int n_quads, slot_stride;
@@ -1694,9 +1725,10 @@ upload_model(ssw_model_s *m)
          * is u (124 |det - d0| + 162 R + 13 |det|) -- folded into c as `bias`, so the key is an
          * upper bound -- plus 97 u |value - d0|, which the kernel adds to the one key it uses as
          * a bound.  Densities whose bias would exceed 4 score units (floored variances far from
-         * the origin) keep mean/det/scale in their record and are evaluated the reference's
-         * way; a non-zero last float marks them. */
+         * the origin) get an inert scan record and go on the codebook's exact-form list: the
+         * kernel evaluates them the reference's way after the scan. */
         std::vector<float> rq(rec.size(), 0.0f), rmax((size_t)ncbf * SSW_REC_FLOATS, 0.0f);
+        std::vector<uint32_t> exl((size_t)ncbf * SSW_EXLIST_STRIDE, 0u);
         const double u24 = 1.0 / 16777216.0;
         int n_exact_form = 0;
         for (int cbf = 0; cbf < ncbf; ++cbf) {
@@ -1719,8 +1751,9 @@ upload_model(ssw_model_s *m)
                 }
                 const double bias = 1.05 * u24 * (124.0 * fabs(delta) + 162.0 * R + 13.0 * fabs(det));
                 if (!finite || !(bias <= 4.0)) {
-                    memcpy(q, r, sizeof(float) * SSW_REC_FLOATS);
-                    q[SSW_REC_FLOATS - 1] = 1.0f;
+                    uint32_t *xl = exl.data() + (size_t)cbf * SSW_EXLIST_STRIDE;
+                    xl[1 + xl[0]++] = (uint32_t)d;
+                    q[SSW_REC_DET] = -3.0e38f; /* a = b = 0: the key stays out of the way */
                     ++n_exact_form;
                     continue;
                 }
@@ -1736,8 +1769,11 @@ upload_model(ssw_model_s *m)
             }
         }
         m->n_exact_form = n_exact_form;
-        if (dev_alloc(&m->d_recq, rq.size()) < 0 || dev_alloc(&m->d_recmax, rmax.size()) < 0)
+        if (dev_alloc(&m->d_recq, rq.size()) < 0 || dev_alloc(&m->d_recmax, rmax.size()) < 0
+            || dev_alloc(&m->d_exlist, exl.size()) < 0)
             return -1;
+        HIP_OK(hipMemcpy(m->d_exlist, exl.data(), exl.size() * sizeof(uint32_t),
+                         hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(m->d_recq, rq.data(), rq.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(m->d_recmax, rmax.data(), rmax.size() * sizeof(float),
                          hipMemcpyHostToDevice));
@@ -1871,6 +1907,7 @@ ssw_model_free(ssw_model_t *m)
     (void)hipFree(m->d_rec);
     (void)hipFree(m->d_recq);
     (void)hipFree(m->d_recmax);
+    (void)hipFree(m->d_exlist);
     (void)hipFree(m->d_mixw);
     (void)hipFree(m->d_ms_pdf);
     (void)hipFree(m->d_sen2cb);
@@ -2091,7 +2128,7 @@ launch_senone(ssw_model_s *m, int scorer, int n_frames, const uint32_t *cw, cons
     /* frames per workgroup: 4 when the batch still leaves >= 2 workgroups per CU, and the
      * prologue can give every (frame, codebook, stream) its own thread */
     int fpb = n_frames >= 4 * 512 ? 4 : 1;
-    size_t lds = 256 + (4 * SSW_MAX_FEAT + 24 * (size_t)m->n_cbf + 16 * sizeof(int)) * fpb + 16;
+    size_t lds = SSW_LOGADD_LDS + (4 * SSW_MAX_FEAT + 24 * (size_t)m->n_cbf + 16 * sizeof(int)) * fpb + 16;
     /* quads per thread: as few as a 1024-thread workgroup allows (measured on MI355X, en-us:
      * R = 2 -> 58 us, 3 -> 59 us, 4 -> 78 us per 4096 frames; more quads per thread only adds
      * register pressure) */
@@ -2229,16 +2266,16 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
         dim3 grid((unsigned)((((int64_t)F.tile_groups * m->n_cbf + 7) / 8) * 8));
         if (two && ms)
             hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 2, true>), grid, dim3(256), 0, st,
-                               m->d_rec, m->d_recq, m->d_recmax, d_feats, F);
+                               m->d_rec, m->d_recq, m->d_recmax, m->d_exlist, d_feats, F);
         else if (two)
             hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 2, false>), grid, dim3(256), 0, st,
-                               m->d_rec, m->d_recq, m->d_recmax, d_feats, F);
+                               m->d_rec, m->d_recq, m->d_recmax, m->d_exlist, d_feats, F);
         else if (ms)
             hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 1, true>), grid, dim3(256), 0, st,
-                               m->d_rec, m->d_recq, m->d_recmax, d_feats, F);
+                               m->d_rec, m->d_recq, m->d_recmax, m->d_exlist, d_feats, F);
         else
             hipLaunchKernelGGL((ptm_topn_frames_kernel<13, 1, false>), grid, dim3(256), 0, st,
-                               m->d_rec, m->d_recq, m->d_recmax, d_feats, F);
+                               m->d_rec, m->d_recq, m->d_recmax, m->d_exlist, d_feats, F);
         HIP_OK(hipGetLastError());
         /* one work item per wave; the list is normally far shorter than the grid */
         int64_t fb = pairs / 64 + 1;
