@@ -1450,10 +1450,65 @@ vit_eval_3st(int &s0, int &s1, int &s2, int &h0, int &h1, int &h2, int &os, int 
     return best;
 }
 
+/* state_align_search_finish (state_align_search.c:215-268): one lane walks the token stack
+ * back from frame n_frames - 2. */
+__device__ __forceinline__ void
+align_backtrace(const AlignParams &P, const AlignUtt &U, int u, const int2 *tok, int n_states,
+                int final_id, int final_score)
+{
+    ssw_align_entry_t *st = P.state_io + (size_t)U.phone_off * 3;
+    int last_id = final_id, cur_id = last_id;
+    int last_score = final_score;
+    int status = 0;
+    if (last_id == -1) {
+        status = -1;
+    } else {
+        int last_frame = U.n_frames;
+        for (int cf = U.n_frames - 2; cf >= 0; --cf) {
+            int2 cur = tok[(size_t)cf * n_states + cur_id];
+            cur_id = cur.x;
+            if (cur_id == -1) {
+                status = -(2 + cf);
+                break;
+            }
+            if (cur_id != last_id) {
+                st[last_id].start = cf + 1;
+                st[last_id].duration = last_frame - (cf + 1);
+                st[last_id].score = last_score - cur.y;
+                last_id = cur_id;
+                last_score = cur.y;
+                last_frame = cf + 1;
+            }
+        }
+        if (status == 0) {
+            st[0].start = 0;
+            st[0].duration = last_frame;
+        }
+    }
+    P.status[u] = status;
+}
+
 /* LDS layout: 16 int arrays of `P` (padded phone count) entries each. */
 enum { A_S0, A_S1, A_S2, A_H0, A_H1, A_H2, A_OS, A_OH, A_FR, A_TPA, A_TPB, A_TPC, A_SEN01,
        A_SEN2, A_SF, A_EF, A_COUNT };
 
+/* WMAX > 0: utterances of up to 64 * WMAX phones; every lane keeps the senone scores of its
+ * phones for the current frame in registers and requests the next frame's at the top of each
+ * frame, so the scattered 2-byte gathers from the score rows (DRAM latency: the rows were
+ * written by another kernel long ago) are a whole frame step ahead of their use.  WMAX == 0:
+ * any phone count, scores fetched where they are used. */
+/* The alignment kernel runs one wave64 per workgroup: LDS operations of a wave are processed in
+ * issue order, so ordering between lanes needs only a compiler-level fence, not s_barrier —
+ * whose __syncthreads() form would also drain the outstanding token stores and score
+ * prefetches every time. */
+__device__ __forceinline__ void
+wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int WMAX>
 __global__ void __launch_bounds__(64)
 viterbi_align_kernel(AlignParams P)
 {
@@ -1494,24 +1549,53 @@ viterbi_align_kernel(AlignParams P)
             L(A_EF, p) = INT_MAX;
         }
     }
-    __syncthreads();
+    wave_sync();
     if (lane == 0) { /* state_align_search_start: hmm_enter(hmms, 0, 0, 0) */
         L(A_S0, 0) = 0;
         L(A_H0, 0) = 0;
         L(A_FR, 0) = 0;
     }
-    __syncthreads();
+    wave_sync();
 
     int2 *tok = P.tokens + U.tok_off;
     int best_score = 0;
+    constexpr int WR = WMAX ? WMAX : 1;
+    int sid01[WR], sid2[WR], cur01[WR], cur2[WR];
+    if (WMAX) {
+        const int16_t *row0 = P.senscr + (size_t)U.frame_off * P.n_sen;
+#pragma unroll
+        for (int w = 0; w < WR; ++w) {
+            int p = w * 64 + lane;
+            bool real = p < NP && U.n_frames > 0;
+            sid01[w] = real ? L(A_SEN01, p) : 0;
+            sid2[w] = real ? L(A_SEN2, p) : 0;
+            cur01[w] = real ? ((int)(uint16_t)row0[sid01[w] & 0xffff]
+                               | ((int)(uint16_t)row0[(sid01[w] >> 16) & 0xffff] << 16))
+                            : 0;
+            cur2[w] = real ? (int)row0[sid2[w]] : 0;
+        }
+    }
     for (int t = 0; t < U.n_frames; ++t) {
         const int16_t *row = P.senscr + (size_t)(U.frame_off + t) * P.n_sen;
         const int nf = t + 1;
+        int nxt01[WR], nxt2[WR];
+        if (WMAX) { /* next frame's scores (the last frame re-reads its own row) */
+            const int16_t *rown = row + (nf < U.n_frames ? (size_t)P.n_sen : 0);
+#pragma unroll
+            for (int w = 0; w < WR; ++w) {
+                bool real = w * 64 + lane < NP;
+                nxt01[w] = real ? ((int)(uint16_t)rown[sid01[w] & 0xffff]
+                                   | ((int)(uint16_t)rown[(sid01[w] >> 16) & 0xffff] << 16))
+                                : 0;
+                nxt2[w] = real ? (int)rown[sid2[w]] : 0;
+            }
+        }
         const bool renorm = (best_score - 0x300000) < SSW_WORST_SCORE;
         int bs = SSW_WORST_SCORE;
 
         /* renormalize_hmms + evaluate_hmms + prune_hmms (state_align_search.c:57-106) */
-        for (int w = 0; w < W; ++w) {
+#pragma unroll
+        for (int w = 0; w < (WMAX ? WMAX : W); ++w) {
             int p = w * 64 + lane;
             if (p < NP) {
                 int s0 = L(A_S0, p), s1 = L(A_S1, p), s2 = L(A_S2, p), os = L(A_OS, p);
@@ -1528,10 +1612,17 @@ viterbi_align_kernel(AlignParams P)
                 }
                 if (fr >= t) {
                     int h0 = L(A_H0, p), h1 = L(A_H1, p), h2 = L(A_H2, p), oh = L(A_OH, p);
-                    int sen01 = L(A_SEN01, p), sen2 = L(A_SEN2, p);
-                    int n0 = -(int)row[sen01 & 0xffff];
-                    int n1 = -(int)row[(sen01 >> 16) & 0xffff];
-                    int n2 = -(int)row[sen2];
+                    int n0, n1, n2;
+                    if (WMAX) {
+                        n0 = -(int)(int16_t)(cur01[w < WR ? w : 0] & 0xffff);
+                        n1 = -(cur01[w < WR ? w : 0] >> 16);
+                        n2 = -cur2[w < WR ? w : 0];
+                    } else {
+                        int sen01 = L(A_SEN01, p), sen2 = L(A_SEN2, p);
+                        n0 = -(int)row[sen01 & 0xffff];
+                        n1 = -(int)row[(sen01 >> 16) & 0xffff];
+                        n2 = -(int)row[sen2];
+                    }
                     int b = vit_eval_3st(s0, s1, s2, h0, h1, h2, os, oh, n0, n1, n2,
                                          (uint32_t)L(A_TPA, p), (uint32_t)L(A_TPB, p),
                                          (uint32_t)L(A_TPC, p));
@@ -1549,7 +1640,7 @@ viterbi_align_kernel(AlignParams P)
             }
         }
         best_score = wave_max_i32(bs);
-        __syncthreads();
+        wave_sync();
 
         /* phone_transition (state_align_search.c:108-133) as a carry chain, then
          * record_transitions (:149-175).  entered(i+1) = C_i & (A_i | entered(i)) is the carry
@@ -1577,7 +1668,7 @@ viterbi_align_kernel(AlignParams P)
                 src_os = L(A_OS, p - 1);
                 src_oh = L(A_OH, p - 1);
             }
-            __syncthreads(); /* all reads of neighbours done before this word's writes */
+            wave_sync(); /* all reads of neighbours done before this word's writes */
             if (valid) {
                 if (entered) { /* hmm_enter, src/hmm.c:142-148 */
                     L(A_S0, p) = src_os;
@@ -1599,46 +1690,396 @@ viterbi_align_kernel(AlignParams P)
                 tkrow[p * 3 + 2] = k2;
             }
             cin = cout;
-            __syncthreads();
+            wave_sync();
+        }
+        if (WMAX) {
+#pragma unroll
+            for (int w = 0; w < WR; ++w) {
+                cur01[w] = nxt01[w];
+                cur2[w] = nxt2[w];
+            }
         }
     }
 
     /* state_align_search_finish (state_align_search.c:215-268) */
     __threadfence();
     __syncthreads();
-    if (lane == 0) {
-        ssw_align_entry_t *st = P.state_io + (size_t)U.phone_off * 3;
-        int last_id = L(A_OH, NP - 1), cur_id = last_id;
-        int last_score = L(A_OS, NP - 1);
-        int status = 0;
-        if (last_id == -1) {
-            status = -1;
-        } else {
-            int last_frame = U.n_frames;
-            for (int cf = U.n_frames - 2; cf >= 0; --cf) {
-                int2 cur = tok[(size_t)cf * n_states + cur_id];
-                cur_id = cur.x;
-                if (cur_id == -1) {
-                    status = -(2 + cf);
-                    break;
+    if (lane == 0)
+        align_backtrace(P, U, u, tok, n_states, L(A_OH, NP - 1), L(A_OS, NP - 1));
+#undef L
+}
+
+/* The same search with every phone's HMM in registers (lane = phone, WMAX words of 64 phones):
+ * nothing of the frame step goes through LDS.  Neighbour values move by one lane with DPP wave
+ * shifts, whose `old` operand supplies the value that crosses a 64-phone word boundary.  All of
+ * phone_transition's reads see the state left by evaluate/prune (as in the reference's loop,
+ * where hmm i+1 is examined before it is entered); the enters are applied afterwards. */
+__device__ __forceinline__ int
+lane_from_next(int v, int edge) /* lane i <- lane i+1, lane 63 <- edge */
+{
+    return __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ int
+lane_from_prev(int v, int edge) /* lane i <- lane i-1, lane 0 <- edge */
+{
+    return __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xf, 0xf, false);
+}
+
+template <int WMAX>
+__global__ void __launch_bounds__(64)
+viterbi_align_reg_kernel(AlignParams P)
+{
+    const int u = blockIdx.x;
+    const int lane = threadIdx.x;
+    const AlignUtt U = P.utts[u];
+    const int NP = U.n_phones;
+    const int n_states = NP * 3;
+
+    int s0[WMAX], s1[WMAX], s2[WMAX], h0[WMAX], h1[WMAX], h2[WMAX], os[WMAX], oh[WMAX], fr[WMAX];
+    uint32_t tpa[WMAX], tpb[WMAX], tpc[WMAX];
+    int sid01[WMAX], sid2[WMAX], sf_next[WMAX], ef[WMAX], cur01[WMAX], cur2[WMAX];
+    const int16_t *row0 = P.senscr + (size_t)U.frame_off * P.n_sen;
+#pragma unroll
+    for (int w = 0; w < WMAX; ++w) {
+        const int p = w * 64 + lane;
+        const bool real = p < NP;
+        const int gp = U.phone_off + (real ? p : 0);
+        s0[w] = s1[w] = s2[w] = os[w] = SSW_WORST_SCORE; /* hmm_clear, src/hmm.c:124-140 */
+        h0[w] = h1[w] = h2[w] = oh[w] = -1;
+        fr[w] = -1;
+        const uint32_t *tp = reinterpret_cast<const uint32_t *>(P.tp) + (size_t)P.tmatid[gp] * 3;
+        tpa[w] = real ? tp[0] : 0u;
+        tpb[w] = real ? tp[1] : 0u;
+        tpc[w] = real ? tp[2] : 0u;
+        sid01[w] = real ? ((int)P.senid[gp * 3] | ((int)P.senid[gp * 3 + 1] << 16)) : 0;
+        sid2[w] = real ? (int)P.senid[gp * 3 + 2] : 0;
+        ef[w] = real ? P.ef[gp] : INT_MAX;
+        sf_next[w] = (p + 1 < NP) ? P.sf[gp + 1] : INT_MAX; /* nothing enters past the end */
+        const bool have = real && U.n_frames > 0;
+        cur01[w] = have ? ((int)(uint16_t)row0[sid01[w] & 0xffff]
+                           | ((int)(uint16_t)row0[(sid01[w] >> 16) & 0xffff] << 16))
+                        : 0;
+        cur2[w] = have ? (int)row0[sid2[w]] : 0;
+    }
+    if (lane == 0) { /* state_align_search_start: hmm_enter(hmms, 0, 0, 0) */
+        s0[0] = 0;
+        h0[0] = 0;
+        fr[0] = 0;
+    }
+
+    int2 *tok = P.tokens + U.tok_off;
+    int best_score = 0;
+    for (int t = 0; t < U.n_frames; ++t) {
+        const int nf = t + 1;
+        const int16_t *rown
+            = P.senscr + (size_t)(U.frame_off + (nf < U.n_frames ? nf : t)) * P.n_sen;
+        int nxt01[WMAX], nxt2[WMAX];
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) {
+            const bool real = w * 64 + lane < NP;
+            nxt01[w] = real ? ((int)(uint16_t)rown[sid01[w] & 0xffff]
+                               | ((int)(uint16_t)rown[(sid01[w] >> 16) & 0xffff] << 16))
+                            : 0;
+            nxt2[w] = real ? (int)rown[sid2[w]] : 0;
+        }
+        const bool renorm = (best_score - 0x300000) < SSW_WORST_SCORE;
+        int bs = SSW_WORST_SCORE;
+
+        /* renormalize_hmms + evaluate_hmms + prune_hmms (state_align_search.c:57-106) */
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) {
+            if (w * 64 + lane < NP) {
+                if (renorm) { /* hmm_normalize, src/hmm.c:150-161 */
+                    if (s0[w] > SSW_WORST_SCORE)
+                        s0[w] -= best_score;
+                    if (s1[w] > SSW_WORST_SCORE)
+                        s1[w] -= best_score;
+                    if (s2[w] > SSW_WORST_SCORE)
+                        s2[w] -= best_score;
+                    if (os[w] > SSW_WORST_SCORE)
+                        os[w] -= best_score;
                 }
-                if (cur_id != last_id) {
-                    st[last_id].start = cf + 1;
-                    st[last_id].duration = last_frame - (cf + 1);
-                    st[last_id].score = last_score - cur.y;
-                    last_id = cur_id;
-                    last_score = cur.y;
-                    last_frame = cf + 1;
+                if (fr[w] >= t) {
+                    const int n0 = -(int)(int16_t)(cur01[w] & 0xffff);
+                    const int n1 = -(cur01[w] >> 16);
+                    const int n2 = -cur2[w];
+                    int b = vit_eval_3st(s0[w], s1[w], s2[w], h0[w], h1[w], h2[w], os[w], oh[w],
+                                         n0, n1, n2, tpa[w], tpb[w], tpc[w]);
+                    bs = b > bs ? b : bs;
+                    if (nf <= ef[w])
+                        fr[w] = nf;
                 }
-            }
-            if (status == 0) {
-                st[0].start = 0;
-                st[0].duration = last_frame;
             }
         }
-        P.status[u] = status;
+        best_score = wave_max_i32(bs);
+
+        /* phone_transition (state_align_search.c:108-133) as a carry chain, then
+         * record_transitions (:149-175).  entered(i+1) = C_i & (A_i | entered(i)) is the carry
+         * recurrence of the binary sum X + Y with X = C, Y = A & C. */
+        unsigned long long Am[WMAX], Cm[WMAX];
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) {
+            const int p = w * 64 + lane;
+            /* frame and entry score of phone p + 1 */
+            const int efr = (w + 1 < WMAX) ? __builtin_amdgcn_readlane(fr[w + 1 < WMAX ? w + 1 : w], 0) : -1;
+            const int es0 = (w + 1 < WMAX) ? __builtin_amdgcn_readlane(s0[w + 1 < WMAX ? w + 1 : w], 0) : 0;
+            const int nfr = lane_from_next(fr[w], efr);
+            const int ns0 = lane_from_next(s0[w], es0);
+            const bool a_bit = p < NP && fr[w] == nf;
+            const bool c_bit = p + 1 < NP && nf >= sf_next[w] && (nfr < t || os[w] > ns0);
+            Am[w] = __ballot(a_bit);
+            Cm[w] = __ballot(c_bit);
+        }
+        unsigned long long cin = 0;
+        int2 *tkrow = tok + (size_t)t * n_states;
+        int prev_os = 0, prev_oh = 0; /* exit score/history of the last phone of the previous word */
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) {
+            const int p = w * 64 + lane;
+            const unsigned long long X = Cm[w], Y = Am[w] & Cm[w];
+            const unsigned long long S = X + Y + cin;
+            const unsigned long long E = S ^ X ^ Y; /* bit i: phone (w*64+i) is entered */
+            cin = ((X & Y) | ((X | Y) & ~S)) >> 63;
+            const bool entered = (E >> lane) & 1ull;
+            const int src_os = lane_from_prev(os[w], prev_os);
+            const int src_oh = lane_from_prev(oh[w], prev_oh);
+            prev_os = __builtin_amdgcn_readlane(os[w], 63);
+            prev_oh = __builtin_amdgcn_readlane(oh[w], 63);
+            if (p < NP) {
+                if (entered) { /* hmm_enter, src/hmm.c:142-148 */
+                    s0[w] = src_os;
+                    h0[w] = src_oh;
+                    fr[w] = nf;
+                }
+                int2 k0 = make_int2(-1, -1), k1 = k0, k2 = k0;
+                if (fr[w] >= t) {
+                    k0 = make_int2(h0[w], s0[w]);
+                    k1 = make_int2(h1[w], s1[w]);
+                    k2 = make_int2(h2[w], s2[w]);
+                    h0[w] = p * 3;
+                    h1[w] = p * 3 + 1;
+                    h2[w] = p * 3 + 2;
+                }
+                tkrow[p * 3] = k0;
+                tkrow[p * 3 + 1] = k1;
+                tkrow[p * 3 + 2] = k2;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) {
+            cur01[w] = nxt01[w];
+            cur2[w] = nxt2[w];
+        }
     }
-#undef L
+
+    /* state_align_search_finish (state_align_search.c:215-268) */
+    const int lw = (NP - 1) >> 6, ll = (NP - 1) & 63;
+    int fin_oh = -1, fin_os = SSW_WORST_SCORE;
+#pragma unroll
+    for (int w = 0; w < WMAX; ++w)
+        if (w == lw) {
+            fin_oh = __shfl(oh[w], ll, WAVE);
+            fin_os = __shfl(os[w], ll, WAVE);
+        }
+    __threadfence();
+    __syncthreads();
+    if (lane == 0)
+        align_backtrace(P, U, u, tok, n_states, fin_oh, fin_os);
+}
+
+/* One wave per 64-phone word of the utterance (workgroup = n_words waves, up to 16): the frame
+ * step of every word runs in parallel, HMMs in registers as above.  Per frame the waves meet
+ * twice at an LDS-only barrier (no drain of the outstanding token stores): once to publish their
+ * boundary values (frame / entry score of their first phone, exit score / history of their last)
+ * and their best score, once to publish the A and C masks of phone_transition, after which every
+ * wave folds the carry chain up to its own word.  The exchange slots are double-buffered by
+ * frame parity: a wave can be at most one barrier ahead of the slowest one. */
+#define SSW_ALIGN_MAX_WAVES 16
+
+__device__ __forceinline__ void
+lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+/* wave-wide maximum with DPP row shifts and row broadcasts (no LDS round trips); uniform result */
+__device__ __forceinline__ int
+wave_max_dpp(int v)
+{
+#define SSW_DPP_MAX(ctrl, rmask)                                                             \
+    {                                                                                        \
+        int o = __builtin_amdgcn_update_dpp(INT_MIN, v, ctrl, rmask, 0xf, false);            \
+        v = o > v ? o : v;                                                                   \
+    }
+    SSW_DPP_MAX(0x111, 0xf) /* row_shr:1 */
+    SSW_DPP_MAX(0x112, 0xf) /* row_shr:2 */
+    SSW_DPP_MAX(0x114, 0xf) /* row_shr:4 */
+    SSW_DPP_MAX(0x118, 0xf) /* row_shr:8: lane 15 of every row holds the row's maximum */
+    SSW_DPP_MAX(0x142, 0xa) /* row_bcast:15 into rows 1 and 3 */
+    SSW_DPP_MAX(0x143, 0xc) /* row_bcast:31 into rows 2 and 3 */
+#undef SSW_DPP_MAX
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+__global__ void __launch_bounds__(64 * SSW_ALIGN_MAX_WAVES)
+viterbi_align_mw_kernel(AlignParams P)
+{
+    __shared__ int x_bs[2][SSW_ALIGN_MAX_WAVES], x_fr0[2][SSW_ALIGN_MAX_WAVES],
+        x_s00[2][SSW_ALIGN_MAX_WAVES], x_os63[2][SSW_ALIGN_MAX_WAVES],
+        x_oh63[2][SSW_ALIGN_MAX_WAVES];
+    __shared__ unsigned long long x_A[2][SSW_ALIGN_MAX_WAVES], x_C[2][SSW_ALIGN_MAX_WAVES];
+    __shared__ int x_fin[2];
+    const int u = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6;
+    const AlignUtt U = P.utts[u];
+    const int NP = U.n_phones;
+    const int n_states = NP * 3;
+    const int p = w * 64 + lane;
+    const bool real = p < NP;
+    const int gp = U.phone_off + (real ? p : 0);
+
+    int s0 = SSW_WORST_SCORE, s1 = SSW_WORST_SCORE, s2 = SSW_WORST_SCORE, os = SSW_WORST_SCORE;
+    int h0 = -1, h1 = -1, h2 = -1, oh = -1, fr = -1; /* hmm_clear, src/hmm.c:124-140 */
+    const uint32_t *tp = reinterpret_cast<const uint32_t *>(P.tp) + (size_t)P.tmatid[gp] * 3;
+    const uint32_t tpa = real ? tp[0] : 0u, tpb = real ? tp[1] : 0u, tpc = real ? tp[2] : 0u;
+    const int sid01 = real ? ((int)P.senid[gp * 3] | ((int)P.senid[gp * 3 + 1] << 16)) : 0;
+    const int sid2 = real ? (int)P.senid[gp * 3 + 2] : 0;
+    const int ef = real ? P.ef[gp] : INT_MAX;
+    const int sf_next = (p + 1 < NP) ? P.sf[gp + 1] : INT_MAX;
+    /* senone scores of this lane's phone: three rotating register sets, so that the scattered
+     * 2-byte gathers of frame t + 2 are requested at the top of frame t (a frame step is shorter
+     * than a DRAM round trip) */
+    const int last = U.n_frames - 1;
+    auto fetch = [&](int t, int &v01, int &v2) {
+        const int16_t *row = P.senscr + (size_t)(U.frame_off + (t < last ? t : last)) * P.n_sen;
+        const bool have = real && U.n_frames > 0;
+        v01 = have ? ((int)(uint16_t)row[sid01 & 0xffff]
+                      | ((int)(uint16_t)row[(sid01 >> 16) & 0xffff] << 16))
+                   : 0;
+        v2 = have ? (int)row[sid2] : 0;
+    };
+    int a01, a2, b01, b2, c01, c2;
+    fetch(0, a01, a2);
+    fetch(1, b01, b2);
+    if (p == 0) { /* state_align_search_start: hmm_enter(hmms, 0, 0, 0) */
+        s0 = 0;
+        h0 = 0;
+        fr = 0;
+    }
+
+    int2 *tok = P.tokens + U.tok_off;
+    int best_score = 0;
+    auto frame = [&](const int t, const int cur01, const int cur2, int &fut01, int &fut2) {
+        const int nf = t + 1, par = t & 1;
+        fetch(t + 2, fut01, fut2);
+        const bool renorm = (best_score - 0x300000) < SSW_WORST_SCORE;
+        int bs = SSW_WORST_SCORE;
+
+        /* renormalize_hmms + evaluate_hmms + prune_hmms (state_align_search.c:57-106) */
+        if (real) {
+            if (renorm) { /* hmm_normalize, src/hmm.c:150-161 */
+                if (s0 > SSW_WORST_SCORE)
+                    s0 -= best_score;
+                if (s1 > SSW_WORST_SCORE)
+                    s1 -= best_score;
+                if (s2 > SSW_WORST_SCORE)
+                    s2 -= best_score;
+                if (os > SSW_WORST_SCORE)
+                    os -= best_score;
+            }
+            if (fr >= t) {
+                const int n0 = -(int)(int16_t)(cur01 & 0xffff);
+                const int n1 = -(cur01 >> 16);
+                const int n2 = -cur2;
+                int b = vit_eval_3st(s0, s1, s2, h0, h1, h2, os, oh, n0, n1, n2, tpa, tpb, tpc);
+                bs = b > bs ? b : bs;
+                if (nf <= ef)
+                    fr = nf;
+            }
+        }
+        bs = wave_max_dpp(bs);
+        if (lane == 0) {
+            x_bs[par][w] = bs;
+            x_fr0[par][w] = fr;
+            x_s00[par][w] = s0;
+        }
+        if (lane == 63) {
+            x_os63[par][w] = os;
+            x_oh63[par][w] = oh;
+        }
+        lds_barrier();
+        best_score = SSW_WORST_SCORE;
+        for (int k = 0; k < nw; ++k) {
+            int v = x_bs[par][k];
+            best_score = v > best_score ? v : best_score;
+        }
+
+        /* phone_transition (state_align_search.c:108-133): A/C masks of this word */
+        const int efr = w + 1 < nw ? x_fr0[par][w + 1] : -1;
+        const int es0 = w + 1 < nw ? x_s00[par][w + 1] : 0;
+        const int nfr = lane_from_next(fr, efr);
+        const int ns0 = lane_from_next(s0, es0);
+        const bool a_bit = real && fr == nf;
+        const bool c_bit = p + 1 < NP && nf >= sf_next && (nfr < t || os > ns0);
+        const unsigned long long Am = __ballot(a_bit), Cm = __ballot(c_bit);
+        if (lane == 0) {
+            x_A[par][w] = Am;
+            x_C[par][w] = Cm;
+        }
+        lds_barrier();
+        /* carry chain over the words before this one, then this word's enters */
+        unsigned long long cin = 0;
+        for (int k = 0; k < w; ++k) {
+            const unsigned long long X = x_C[par][k], Y = x_A[par][k] & X;
+            const unsigned long long S = X + Y + cin;
+            cin = ((X & Y) | ((X | Y) & ~S)) >> 63;
+        }
+        const unsigned long long X = Cm, Y = Am & Cm;
+        const unsigned long long E = (X + Y + cin) ^ X ^ Y; /* bit i: phone (w*64+i) is entered */
+        const bool entered = (E >> lane) & 1ull;
+        const int src_os = lane_from_prev(os, w > 0 ? x_os63[par][w > 0 ? w - 1 : 0] : 0);
+        const int src_oh = lane_from_prev(oh, w > 0 ? x_oh63[par][w > 0 ? w - 1 : 0] : 0);
+        if (real) { /* record_transitions (:149-175) */
+            if (entered) { /* hmm_enter, src/hmm.c:142-148 */
+                s0 = src_os;
+                h0 = src_oh;
+                fr = nf;
+            }
+            int2 k0 = make_int2(-1, -1), k1 = k0, k2 = k0;
+            if (fr >= t) {
+                k0 = make_int2(h0, s0);
+                k1 = make_int2(h1, s1);
+                k2 = make_int2(h2, s2);
+                h0 = p * 3;
+                h1 = p * 3 + 1;
+                h2 = p * 3 + 2;
+            }
+            int2 *tkrow = tok + (size_t)t * n_states;
+            tkrow[p * 3] = k0;
+            tkrow[p * 3 + 1] = k1;
+            tkrow[p * 3 + 2] = k2;
+        }
+    };
+    for (int t = 0; t < U.n_frames; t += 3) { /* the same trip count in every wave: barriers */
+        frame(t, a01, a2, c01, c2);
+        if (t + 1 < U.n_frames)
+            frame(t + 1, b01, b2, a01, a2);
+        if (t + 2 < U.n_frames)
+            frame(t + 2, c01, c2, b01, b2);
+    }
+
+    /* state_align_search_finish (state_align_search.c:215-268) */
+    if (p == NP - 1) {
+        x_fin[0] = oh;
+        x_fin[1] = os;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        align_backtrace(P, U, u, tok, n_states, x_fin[0], x_fin[1]);
 }
 
 } // namespace
@@ -1677,6 +2118,9 @@ struct ssw_model_s {
     /* optional per-kernel event timing */
     int timing;
     hipEvent_t ev[3];
+    /* alignment workspace (ssw_align_batch) */
+    unsigned char *d_align_ws;
+    size_t align_ws_bytes;
     /* host-API staging */
     float *d_feats;
     int16_t *d_out;
@@ -1908,6 +2352,7 @@ ssw_model_free(ssw_model_t *m)
     (void)hipFree(m->d_recq);
     (void)hipFree(m->d_recmax);
     (void)hipFree(m->d_exlist);
+    (void)hipFree(m->d_align_ws);
     (void)hipFree(m->d_mixw);
     (void)hipFree(m->d_ms_pdf);
     (void)hipFree(m->d_sen2cb);
@@ -2453,30 +2898,48 @@ ssw_align_batch(ssw_model_t *m, const int16_t *d_senscr, int32_t n_utts,
             return -1;
         }
     size_t lds = (size_t)A_COUNT * (max_phones + 1) * sizeof(int);
-    if (lds > 160 * 1024) {
+    if (max_phones > 64 * SSW_ALIGN_MAX_WAVES && lds > 160 * 1024) {
         ssw_set_error("utterance with %d phones exceeds the LDS-resident limit", max_phones);
         return -1;
     }
-    AlignUtt *d_utts = NULL;
-    uint16_t *d_senid = NULL;
-    int16_t *d_tmatid = NULL;
-    int32_t *d_sf = NULL, *d_ef = NULL, *d_status = NULL;
-    int2 *d_tok = NULL;
-    ssw_align_entry_t *d_state = NULL;
+    /* one grow-only device arena per model for the call's inputs, token stacks and results */
+    size_t off = 0;
+    auto carve = [&off](size_t bytes) {
+        size_t at = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    const size_t o_utts = carve(sizeof(AlignUtt) * n_utts);
+    const size_t o_senid = carve(sizeof(uint16_t) * 3 * (size_t)total_phones + 16);
+    const size_t o_tmatid = carve(sizeof(int16_t) * (size_t)total_phones + 16);
+    const size_t o_sf = carve(sizeof(int32_t) * (size_t)total_phones);
+    const size_t o_ef = carve(sizeof(int32_t) * (size_t)total_phones);
+    const size_t o_status = carve(sizeof(int32_t) * n_utts);
+    const size_t o_state = carve(sizeof(ssw_align_entry_t) * 3 * (size_t)total_phones);
+    const size_t o_tok = carve(sizeof(int2) * (size_t)(tok_total > 0 ? tok_total : 1));
     int rv = -1;
 #define TRY(expr)                                                                            \
     if ((expr) != hipSuccess) {                                                              \
         ssw_set_error("%s failed: %s", #expr, hipGetErrorString(hipGetLastError()));         \
         goto out;                                                                            \
     }
-    TRY(hipMalloc((void **)&d_utts, sizeof(AlignUtt) * n_utts));
-    TRY(hipMalloc((void **)&d_senid, sizeof(uint16_t) * 3 * (size_t)total_phones + 16));
-    TRY(hipMalloc((void **)&d_tmatid, sizeof(int16_t) * (size_t)total_phones + 16));
-    TRY(hipMalloc((void **)&d_sf, sizeof(int32_t) * (size_t)total_phones));
-    TRY(hipMalloc((void **)&d_ef, sizeof(int32_t) * (size_t)total_phones));
-    TRY(hipMalloc((void **)&d_status, sizeof(int32_t) * n_utts));
-    TRY(hipMalloc((void **)&d_tok, sizeof(int2) * (size_t)(tok_total > 0 ? tok_total : 1)));
-    TRY(hipMalloc((void **)&d_state, sizeof(ssw_align_entry_t) * 3 * (size_t)total_phones));
+    if (off > m->align_ws_bytes) {
+        (void)hipFree(m->d_align_ws);
+        m->d_align_ws = NULL;
+        m->align_ws_bytes = 0;
+        TRY(hipMalloc((void **)&m->d_align_ws, off));
+        m->align_ws_bytes = off;
+    }
+    {
+    unsigned char *ws = m->d_align_ws;
+    AlignUtt *d_utts = reinterpret_cast<AlignUtt *>(ws + o_utts);
+    uint16_t *d_senid = reinterpret_cast<uint16_t *>(ws + o_senid);
+    int16_t *d_tmatid = reinterpret_cast<int16_t *>(ws + o_tmatid);
+    int32_t *d_sf = reinterpret_cast<int32_t *>(ws + o_sf);
+    int32_t *d_ef = reinterpret_cast<int32_t *>(ws + o_ef);
+    int32_t *d_status = reinterpret_cast<int32_t *>(ws + o_status);
+    ssw_align_entry_t *d_state = reinterpret_cast<ssw_align_entry_t *>(ws + o_state);
+    int2 *d_tok = reinterpret_cast<int2 *>(ws + o_tok);
     TRY(hipMemcpyAsync(d_utts, utts.data(), sizeof(AlignUtt) * n_utts, hipMemcpyHostToDevice, st));
     TRY(hipMemcpyAsync(d_senid, senid, sizeof(uint16_t) * 3 * (size_t)total_phones,
                        hipMemcpyHostToDevice, st));
@@ -2501,27 +2964,39 @@ ssw_align_batch(ssw_model_t *m, const int16_t *d_senscr, int32_t n_utts,
         A.n_sen = h->n_sen;
         A.n_utts = n_utts;
         A.max_phones = max_phones;
-        if (lds > 64 * 1024)
-            TRY(hipFuncSetAttribute((const void *)viterbi_align_kernel,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(viterbi_align_kernel, dim3(n_utts), dim3(64), lds, st, A);
-        TRY(hipGetLastError());
+        const int words = (max_phones + 63) / 64;
+        /* HMMs in registers: one wave per 64-phone word when the batch leaves SIMDs idle (the
+         * usual case: a frame step is a short dependent chain), one wave per utterance for very
+         * large batches; utterances beyond 1024 phones go through LDS */
+        const char *mode = getenv("SSW_ALIGN_KERNEL"); /* "lds", "reg", "mw": tests and tuning */
+        if (words <= SSW_ALIGN_MAX_WAVES && !(mode && (!strcmp(mode, "lds") || !strcmp(mode, "reg")))
+            && (words > 4 || (int64_t)n_utts * words <= 8192 || (mode && !strcmp(mode, "mw")))) {
+            hipLaunchKernelGGL(viterbi_align_mw_kernel, dim3(n_utts), dim3(64 * words), 0, st, A);
+            TRY(hipGetLastError());
+        } else {
+            const bool in_regs = words <= 4 && !(mode && !strcmp(mode, "lds"));
+            void (*kern)(AlignParams) = words <= 1 ? viterbi_align_reg_kernel<1>
+                : words <= 2                       ? viterbi_align_reg_kernel<2>
+                : words <= 4                       ? viterbi_align_reg_kernel<4>
+                : words <= 8                       ? viterbi_align_kernel<8>
+                                                   : viterbi_align_kernel<0>;
+            if (!in_regs && words <= 4)
+                kern = viterbi_align_kernel<4>;
+            if (!in_regs && lds > 64 * 1024)
+                TRY(hipFuncSetAttribute((const void *)kern,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(n_utts), dim3(64), in_regs ? 0 : lds, st, A);
+            TRY(hipGetLastError());
+        }
     }
     TRY(hipMemcpyAsync(state_io, d_state, sizeof(ssw_align_entry_t) * 3 * (size_t)total_phones,
                        hipMemcpyDeviceToHost, st));
     TRY(hipMemcpyAsync(status, d_status, sizeof(int32_t) * n_utts, hipMemcpyDeviceToHost, st));
     TRY(hipStreamSynchronize(st));
     rv = 0;
+    }
 out:
 #undef TRY
-    (void)hipFree(d_utts);
-    (void)hipFree(d_senid);
-    (void)hipFree(d_tmatid);
-    (void)hipFree(d_sf);
-    (void)hipFree(d_ef);
-    (void)hipFree(d_status);
-    (void)hipFree(d_tok);
-    (void)hipFree(d_state);
     return rv;
 }
 

@@ -14,7 +14,8 @@ def _random_senscr(n_frames, n_sen, seed):
     return scr
 
 
-@pytest.mark.parametrize("n_phones,n_frames", [(1, 5), (5, 40), (64, 300), (65, 300), (150, 700)])
+@pytest.mark.parametrize("n_phones,n_frames", [(1, 5), (5, 40), (64, 300), (65, 300), (128, 500), (129, 500), (150, 700), (256, 900),
+                          (257, 900), (513, 1700)])
 def test_align_matches_oracle(gpu_en, orc_en, n_phones, n_frames):
     senid, tmat, _ = synth_alignment_task(orc_en.sseq, orc_en.phone_ssid, orc_en.phone_tmat,
                                           orc_en.n_ciphone, n_phones, 99 + n_phones)
@@ -28,3 +29,62 @@ def test_align_matches_oracle(gpu_en, orc_en, n_phones, n_frames):
     assert (status[0] == 0) == (rv == 0)
     if rv == 0:
         assert np.array_equal(st, rst)
+
+
+def test_all_alignment_kernels_agree_on_a_ragged_windowed_batch(gpu_en, orc_en, monkeypatch):
+    """Utterances of 1..200 phones in one call, with phone windows (sf/ef) on some of them and
+    one window that cannot be met: the wave-per-word kernel (the default here), the
+    wave-per-utterance register kernel and the LDS kernel (SSW_ALIGN_KERNEL=mw/reg/lds) must all
+    equal the oracle, failures included."""
+    rng = np.random.default_rng(5)
+    n_ph = [1, 3, 64, 65, 127, 128, 200, 17]
+    n_fr = [int(p * rng.integers(3, 6) + 4) for p in n_ph]
+    frame_off = np.concatenate([[0], np.cumsum(n_fr)]).astype(np.int32)
+    phone_off = np.concatenate([[0], np.cumsum(n_ph)]).astype(np.int32)
+    scr = _random_senscr(int(frame_off[-1]), orc_en.n_sen, 31)
+    senid, tmat, sf, ef = [], [], [], []
+    for u, (p, f) in enumerate(zip(n_ph, n_fr)):
+        s, t, _ = synth_alignment_task(orc_en.sseq, orc_en.phone_ssid, orc_en.phone_tmat,
+                                       orc_en.n_ciphone, p, 400 + u)
+        senid.append(s)
+        tmat.append(t)
+        a = np.zeros(p, np.int32)
+        b = np.full(p, 2**31 - 1, np.int32)
+        if u % 2 == 1:  # loose windows around an even split
+            mid = (np.arange(p) * f) // p
+            a = np.maximum(mid - 6, 0).astype(np.int32)
+            b = np.minimum(mid + f // p + 8, f).astype(np.int32)
+        if u == len(n_ph) - 1:  # phone 3 may not start before the last frame: no path
+            a[3:] = f
+        sf.append(a)
+        ef.append(b)
+    senid, tmat = np.concatenate(senid), np.concatenate(tmat)
+    sf, ef = np.concatenate(sf), np.concatenate(ef)
+    ref = []
+    for u in range(len(n_ph)):
+        sl = slice(phone_off[u], phone_off[u + 1])
+        ref.append(orc_en.state_align(scr[frame_off[u]:frame_off[u + 1]], senid[sl], tmat[sl],
+                                      sf=sf[sl], ef=ef[sl]))
+    d = gpu_en.to_device(scr)
+    try:
+        results = []
+        for mode in ("mw", "reg", "lds"):
+            monkeypatch.setenv("SSW_ALIGN_KERNEL", mode)
+            results.append(gpu_en.align_batch(d, frame_off, phone_off, senid, tmat, sf=sf, ef=ef))
+    finally:
+        gpu_en.device_free(d)
+    assert any(r[0] != 0 for r in ref) and any(r[0] == 0 for r in ref)
+    for st, status in results:
+        for u, (rv, rst, _) in enumerate(ref):
+            assert (status[u] == 0) == (rv == 0), u
+            if rv == 0:
+                assert np.array_equal(st[phone_off[u] * 3:phone_off[u + 1] * 3], rst), u
+    assert np.array_equal(results[0][1], results[1][1])
+    assert np.array_equal(results[0][1], results[2][1])
+
+
+@pytest.mark.parametrize("mode", ["reg", "lds"])
+def test_other_alignment_kernels_match_oracle(gpu_en, orc_en, monkeypatch, mode):
+    monkeypatch.setenv("SSW_ALIGN_KERNEL", mode)
+    for n_phones, n_frames in ((64, 300), (65, 300), (150, 700), (256, 900)):
+        test_align_matches_oracle(gpu_en, orc_en, n_phones, n_frames)
