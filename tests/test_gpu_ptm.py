@@ -64,3 +64,41 @@ def test_ptm_correlated_frames_bit_exact(gpu_en, orc_en, means_en):
     got = gpu_en.score_batch(feats)
     ref = orc_en.ptm_score_utt(feats)
     assert np.array_equal(got, ref)
+
+
+def test_ptm_scan_bound_stress(gpu_en, orc_en, means_en):
+    """Inputs chosen against the speculative scan's quadratic form and its error bound: features
+    far from every mean (large cancellation in a*x + b*x^2), tiny features, frames sitting on
+    the means of the ill-conditioned densities the scan leaves to the exact form (floored
+    variances), midpoints between two densities of a codebook (near-ties between candidates),
+    and exact repeats.  All of it must still be bit-exact, top-N order included."""
+    rng = np.random.default_rng(2024)
+    base = synth_features(means_en, 64, 4321)
+    var = orc_en.var.reshape(means_en.shape)
+    parts = [base * 8.0, base * 40.0, base * 0.01, -base, np.zeros((4, 39), np.float32)]
+    # frames on (and a hair off) the means of the densities with the largest precision terms
+    flat = np.argsort(var.max(axis=3).reshape(-1))[-48:]
+    on_mean = np.empty((len(flat), 39), np.float32)
+    for i, k in enumerate(flat):
+        cb, f, d = np.unravel_index(k, var.shape[:3])
+        row = base[i % len(base)].copy()
+        row[f * 13:(f + 1) * 13] = means_en[cb, f, d]
+        on_mean[i] = row
+    parts += [on_mean, on_mean + np.float32(1e-3), on_mean * np.float32(1.0001)]
+    # midpoints of density pairs inside one codebook, all three streams at once
+    mid = np.empty((64, 39), np.float32)
+    for i in range(64):
+        cb = int(rng.integers(0, means_en.shape[0]))
+        for f in range(3):
+            d1, d2 = rng.choice(means_en.shape[2], 2, replace=False)
+            mid[i, f * 13:(f + 1) * 13] = (means_en[cb, f, d1] + means_en[cb, f, d2]) * 0.5
+    parts += [mid, np.repeat(mid[:3], 5, axis=0)]
+    feats = np.ascontiguousarray(np.concatenate(parts), np.float32)
+    assert np.isfinite(feats).all()
+    got = gpu_en.score_batch(feats)
+    flagged, pairs = gpu_en.last_stats()
+    gcw, _ = gpu_en.last_topn(len(feats))
+    ref, rcw, _ = orc_en.ptm_score_utt(feats, want_topn=True)
+    assert np.array_equal(gcw.astype(np.int32), rcw)
+    assert np.array_equal(got, ref)
+    assert flagged < pairs // 4, "the proof should still cover most pairs on these inputs"
