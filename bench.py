@@ -100,7 +100,10 @@ def main():
     from soundswallower_amd.parallel import shard_utterances
     from soundswallower_amd.synth import read_raw_means as raw_means
 
-    _lib.build()
+    if rank == 0:          # one rank compiles (a no-op when the .so is current); the rest wait
+        _lib.build()
+    if dist:
+        dist.barrier()
     mdir = ssw.model_dir(args.model)
     model = ssw.Model(mdir, config={"device": local_rank})
     means = raw_means(mdir)
@@ -205,7 +208,7 @@ def main():
                       if valu_instr else None),
         "exact_pass_share": flagged / max(pairs, 1),
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(mdir, feats, utt_off)
     print(json.dumps(out), flush=True)
     if dist:

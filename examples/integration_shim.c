@@ -1,0 +1,122 @@
+/* integration_shim.c -- the binding INTEGRATION.md describes, as a translation unit a
+ * SoundSwallower maintainer could add to the reference's src/.  It is compiled (syntax and layout
+ * checks only, never linked into this repository's product) by tests/test_integration_shim.py
+ * against the reference's public headers where /root/reference is available:
+ *
+ *     gcc -fsyntax-only -I<reference>/include -Iinclude examples/integration_shim.c
+ *
+ * The static assertions are the drop-in claims of include/ssw_amd.h: ssw_mgau_t can be stored in
+ * acmod->mgau because it starts with the same two members as mgau_t, and its vtable has
+ * mgaufuncs_t's slots in mgaufuncs_t's order (include/soundswallower/acmod.h:93-111). */
+#include <stddef.h>
+#include <stdio.h>
+
+#include <soundswallower/acmod.h>
+#include <soundswallower/alignment.h>
+#include <soundswallower/ckd_alloc.h>
+#include <soundswallower/configuration.h>
+#include <soundswallower/decoder.h>
+#include <soundswallower/err.h>
+
+#include "ssw_amd.h"
+
+_Static_assert(offsetof(ssw_mgau_t, vt) == offsetof(mgau_t, vt), "vtable pointer first");
+_Static_assert(offsetof(ssw_mgau_t, frame_idx) == offsetof(mgau_t, frame_idx), "frame_idx second");
+_Static_assert(offsetof(ssw_mgaufuncs_t, name) == offsetof(mgaufuncs_t, name), "slot 0: name");
+_Static_assert(offsetof(ssw_mgaufuncs_t, frame_eval) == offsetof(mgaufuncs_t, frame_eval),
+               "slot 1: frame_eval");
+_Static_assert(offsetof(ssw_mgaufuncs_t, transform) == offsetof(mgaufuncs_t, transform),
+               "slot 2: transform");
+_Static_assert(offsetof(ssw_mgaufuncs_t, free) == offsetof(mgaufuncs_t, free), "slot 3: free");
+_Static_assert(sizeof(ssw_mgaufuncs_t) == sizeof(mgaufuncs_t), "no extra slots");
+
+static ssw_model_t *gpu_model;
+
+/* swap the CPU scorer for the GPU one after decoder_init() */
+int
+use_gpu_scorer(decoder_t *d, const char *hmmdir)
+{
+    ssw_config_t cfg;
+    char mdef[512], mean[512], var[512], sendump[512], tmat[512];
+    ssw_mgau_t *g;
+
+    ssw_config_defaults(&cfg);
+    cfg.logbase = config_float(d->config, "logbase");
+    cfg.varfloor = config_float(d->config, "varfloor");
+    cfg.mixwfloor = config_float(d->config, "mixwfloor");
+    cfg.tmatfloor = config_float(d->config, "tmatfloor");
+    cfg.topn = config_int(d->config, "topn");
+    cfg.ds = config_int(d->config, "ds");
+    cfg.aw = config_int(d->config, "aw");
+    snprintf(mdef, sizeof mdef, "%s/mdef", hmmdir);
+    snprintf(mean, sizeof mean, "%s/means", hmmdir);
+    snprintf(var, sizeof var, "%s/variances", hmmdir);
+    snprintf(sendump, sizeof sendump, "%s/sendump", hmmdir);
+    snprintf(tmat, sizeof tmat, "%s/transition_matrices", hmmdir);
+    gpu_model = ssw_model_load(mdef, mean, var, sendump, NULL, tmat, &cfg);
+    if (gpu_model == NULL) {
+        E_ERROR("GPU model: %s\n", ssw_last_error());
+        return -1;
+    }
+    g = ssw_ptm_mgau_init(gpu_model); /* stands in for ptm_mgau_init(acmod) */
+    if (g == NULL)
+        return -1;
+    ps_mgau_free(d->acmod->mgau);
+    d->acmod->mgau = (mgau_t *)g; /* same leading layout, same vtable slots */
+    d->acmod->compallsen = TRUE;  /* the GPU scorer computes all senones */
+    return 0;
+}
+
+/* hand the whole utterance over once the features exist */
+void
+prescore_utterance(acmod_t *acmod)
+{
+    ssw_mgau_prescore((ssw_mgau_t *)acmod->mgau, acmod->feat_buf[0][0], acmod->n_feat_frame);
+}
+
+/* the second pass of decoder_alignment on the GPU */
+int
+gpu_second_pass(decoder_t *d, alignment_t *al, int n_frames)
+{
+    int n = alignment_n_phones(al), i = 0, rv = 0;
+    int32 *ssid = ckd_calloc(n, sizeof(*ssid)), *tmatid = ckd_calloc(n, sizeof(*tmatid));
+    int32 *start = ckd_calloc(n, sizeof(*start)), *dur = ckd_calloc(n, sizeof(*dur));
+    alignment_iter_t *it;
+    ssw_state_align_search_t *s;
+    const ssw_align_entry_t *st;
+    int32 ns;
+    int f;
+
+    for (it = alignment_phones(al); it; it = alignment_iter_next(it), ++i) {
+        alignment_entry_t *e = alignment_iter_get(it);
+        ssid[i] = e->id.pid.ssid;
+        tmatid[i] = e->id.pid.tmatid;
+        start[i] = e->start;
+        dur[i] = e->duration;
+    }
+    s = ssw_state_align_search_init(gpu_model, (ssw_mgau_t *)d->acmod->mgau, n, ssid, tmatid,
+                                    start, dur);
+    ssw_state_align_search_start(s);
+    for (f = 0; f < n_frames; ++f) /* the acmod_score/step loop of src/decoder.c:789-793 */
+        ssw_state_align_search_step(s, d->acmod->feat_buf[f][0], f);
+    if (ssw_state_align_search_finish(s) < 0) {
+        E_ERROR("%s\n", ssw_last_error());
+        rv = -1;
+    }
+    st = ssw_state_align_search_states(s, &ns);
+    i = 0;
+    for (it = alignment_states(al); rv == 0 && it; it = alignment_iter_next(it), ++i) {
+        alignment_entry_t *e = alignment_iter_get(it);
+        e->start = st[i].start;
+        e->duration = st[i].duration;
+        e->score = st[i].score;
+    }
+    if (rv == 0)
+        alignment_propagate(al);
+    ssw_state_align_search_free(s);
+    ckd_free(ssid);
+    ckd_free(tmatid);
+    ckd_free(start);
+    ckd_free(dur);
+    return rv;
+}

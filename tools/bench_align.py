@@ -48,7 +48,10 @@ def main():
         else:
             dist.init_process_group(a.backend)
     from soundswallower_amd.parallel import gather_alignments, shard_utterances
-    _lib.build()
+    if rank == 0:
+        _lib.build()
+    if dist:
+        dist.barrier()
     L = _lib.lib()
     mdir = ssw.model_dir("en-us")
     m = ssw.Model(mdir, config={"device": local_rank})
