@@ -96,6 +96,32 @@ wave_max_i32(int v)
     return v;
 }
 
+/* workgroup barrier that orders LDS traffic only (no wait for outstanding global loads/stores) */
+__device__ __forceinline__ void
+lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+/* wave-wide maximum with DPP row shifts and row broadcasts (no LDS round trips); uniform result */
+__device__ __forceinline__ int
+wave_max_dpp(int v)
+{
+#define SSW_DPP_MAX(ctrl, rmask)                                                             \
+    {                                                                                        \
+        int o = __builtin_amdgcn_update_dpp(INT_MIN, v, ctrl, rmask, 0xf, false);            \
+        v = o > v ? o : v;                                                                   \
+    }
+    SSW_DPP_MAX(0x111, 0xf) /* row_shr:1 */
+    SSW_DPP_MAX(0x112, 0xf) /* row_shr:2 */
+    SSW_DPP_MAX(0x114, 0xf) /* row_shr:4 */
+    SSW_DPP_MAX(0x118, 0xf) /* row_shr:8: lane 15 of every row holds the row's maximum */
+    SSW_DPP_MAX(0x142, 0xa) /* row_bcast:15 into rows 1 and 3 */
+    SSW_DPP_MAX(0x143, 0xc) /* row_bcast:31 into rows 2 and 3 */
+#undef SSW_DPP_MAX
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 /* ---------------------------------------------------------------------------------- */
 /* K1a: exact frame-sequential top-N for one (utterance, codebook, stream) chain        */
 /* ---------------------------------------------------------------------------------- */
@@ -424,6 +450,7 @@ ptm_topn_fixup_kernel(ChainParams P, unsigned long long *n_fixed)
  */
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4))); /* 4-byte aligned float4 */
+typedef short short4u __attribute__((ext_vector_type(4), aligned(2))); /* 2-byte aligned 4 x int16 */
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 struct FramesParams {
@@ -444,8 +471,10 @@ med3f(float a, float b, float c)
 
 #define SSW_EXLIST_STRIDE 132 /* [0] count, [1..] codewords the scan leaves to the exact form */
 
+#if defined(SSW_TIMELINE) || defined(SSW_TIMELINE_SEN)
+__device__ unsigned long long g_timeline[16384 * 6];
+#endif
 #ifdef SSW_TIMELINE
-__device__ unsigned long long g_timeline[8192 * 6];
 #define SSW_TL(k)                                                                            \
     if (lane == 0) {                                                                         \
         int wv = blockIdx.x * 4 + (threadIdx.x >> 6);                                        \
@@ -850,6 +879,17 @@ template <int TOPN, int R, int FPB, int NF>
 __global__ void __launch_bounds__(SEN_MAX_THREADS)
 ptm_senone_kernel(SenoneParams P)
 {
+#ifdef SSW_TIMELINE_SEN
+#define STL(k)                                                                               \
+    if ((threadIdx.x & 63) == 0) {                                                           \
+        int wv = blockIdx.x * 11 + (threadIdx.x >> 6);                                       \
+        if (wv < 16384)                                                                      \
+            g_timeline[wv * 6 + (k)] = __builtin_amdgcn_s_memtime();                        \
+    }
+#else
+#define STL(k)
+#endif
+    STL(0)
     /* NF = number of streams when known at compile time (0 = read it from P): with a constant
      * trip count the 12 row loads of a quad are all issued before the first log-add */
     const int n_feat = NF ? NF : P.n_feat;
@@ -923,6 +963,7 @@ ptm_senone_kernel(SenoneParams P)
     }
     __syncthreads();
 
+    STL(1)
     /* senone combine, src/ptm_mgau.c:342-395 */
     int asc[R][FPB][4];
     int best[FPB];
@@ -1002,56 +1043,59 @@ ptm_senone_kernel(SenoneParams P)
             }
         }
     }
-    /* block minimum of every frame */
+    STL(2)
+    /* block minimum of every frame: wave minimum by DPP, one LDS word per (frame, wave), one
+     * barrier, then every wave folds the partials itself */
 #pragma unroll
     for (int fr = 0; fr < FPB; ++fr) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            int o = __shfl_xor(best[fr], off, WAVE);
-            best[fr] = o < best[fr] ? o : best[fr];
-        }
+        const int wmin = -wave_max_dpp(-best[fr]); /* best >= INT_MIN + 1 */
         if ((tid & 63) == 0)
-            s_red[fr * 16 + (tid >> 6)] = best[fr];
+            s_red[fr * 16 + (tid >> 6)] = wmin;
     }
     __syncthreads();
-    if (tid < 64) {
 #pragma unroll
-        for (int fr = 0; fr < FPB; ++fr) {
-            int b = tid < (nthr >> 6) ? s_red[fr * 16 + tid] : INT_MAX;
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) {
-                int o = __shfl_xor(b, off, WAVE);
-                b = o < b ? o : b;
-            }
-            best[fr] = b;
+    for (int fr = 0; fr < FPB; ++fr) {
+        int b = INT_MAX;
+        for (int k = 0; k < (nthr >> 6); ++k) {
+            const int o = s_red[fr * 16 + k];
+            b = o < b ? o : b;
         }
+        best[fr] = b;
     }
-    __syncthreads();
-    if (tid == 0) {
-#pragma unroll
-        for (int fr = 0; fr < FPB; ++fr)
-            s_red[fr * 16] = best[fr];
-    }
-    __syncthreads();
+    STL(3)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int q = r * nthr + tid;
         if (q < P.n_quads) {
             const short4 sen = P.slot_sen[q];
             const int sj[4] = { sen.x, sen.y, sen.z, sen.w };
+            const bool run4 = sj[0] >= 0 && sj[1] == sj[0] + 1 && sj[2] == sj[0] + 2
+                && sj[3] == sj[0] + 3;
 #pragma unroll
             for (int fr = 0; fr < FPB; ++fr) {
                 if (fr < nfr) {
-                    const int b = s_red[fr * 16];
+                    const int b = best[fr];
                     int16_t *orow = P.out + (size_t)(t0 + fr) * P.n_sen;
+                    int16_t v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (sj[j] >= 0) /* int16 arithmetic as in src/ptm_mgau.c:394-400 */
-                            orow[sj[j]] = (int16_t)((int16_t)asc[r][fr][j] - (int16_t)b);
+                    for (int j = 0; j < 4; ++j) /* int16 arithmetic as in src/ptm_mgau.c:394-400 */
+                        v[j] = (int16_t)((int16_t)asc[r][fr][j] - (int16_t)b);
+                    if (run4) { /* 4 consecutive senone ids (19 quads in 20): one 8-byte store,
+                                 * neighbouring lanes write neighbouring chunks */
+                        short4u pk = { v[0], v[1], v[2], v[3] };
+                        *reinterpret_cast<short4u *>(orow + sj[0]) = pk;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (sj[j] >= 0)
+                                orow[sj[j]] = v[j];
+                    }
                 }
             }
         }
     }
+    STL(4)
+#undef STL
 }
 
 /* One frame with an explicit active set: the compallsen = no half of ptm_mgau_frame_eval
@@ -1897,31 +1941,6 @@ viterbi_align_reg_kernel(AlignParams P)
  * frame parity: a wave can be at most one barrier ahead of the slowest one. */
 #define SSW_ALIGN_MAX_WAVES 16
 
-__device__ __forceinline__ void
-lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-/* wave-wide maximum with DPP row shifts and row broadcasts (no LDS round trips); uniform result */
-__device__ __forceinline__ int
-wave_max_dpp(int v)
-{
-#define SSW_DPP_MAX(ctrl, rmask)                                                             \
-    {                                                                                        \
-        int o = __builtin_amdgcn_update_dpp(INT_MIN, v, ctrl, rmask, 0xf, false);            \
-        v = o > v ? o : v;                                                                   \
-    }
-    SSW_DPP_MAX(0x111, 0xf) /* row_shr:1 */
-    SSW_DPP_MAX(0x112, 0xf) /* row_shr:2 */
-    SSW_DPP_MAX(0x114, 0xf) /* row_shr:4 */
-    SSW_DPP_MAX(0x118, 0xf) /* row_shr:8: lane 15 of every row holds the row's maximum */
-    SSW_DPP_MAX(0x142, 0xa) /* row_bcast:15 into rows 1 and 3 */
-    SSW_DPP_MAX(0x143, 0xc) /* row_bcast:31 into rows 2 and 3 */
-#undef SSW_DPP_MAX
-    return __builtin_amdgcn_readlane(v, 63);
-}
-
 __global__ void __launch_bounds__(64 * SSW_ALIGN_MAX_WAVES)
 viterbi_align_mw_kernel(AlignParams P)
 {
@@ -2743,9 +2762,9 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
         return -1;
     if (m->timing)
         HIP_OK(hipEventRecord(m->ev[2], st));
-#ifdef SSW_TIMELINE
+#if defined(SSW_TIMELINE) || defined(SSW_TIMELINE_SEN)
     if (getenv("SSW_TIMELINE_OUT")) {
-        std::vector<unsigned long long> tl(8192 * 6);
+        std::vector<unsigned long long> tl(16384 * 6);
         HIP_OK(hipStreamSynchronize(st));
         HIP_OK(hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_timeline), tl.size() * 8));
         FILE *fp = fopen(getenv("SSW_TIMELINE_OUT"), "wb");
