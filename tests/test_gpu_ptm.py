@@ -102,3 +102,23 @@ def test_ptm_scan_bound_stress(gpu_en, orc_en, means_en):
     assert np.array_equal(gcw.astype(np.int32), rcw)
     assert np.array_equal(got, ref)
     assert flagged < pairs // 4, "the proof should still cover most pairs on these inputs"
+
+
+def test_ptm_large_batch_is_size_independent(gpu_en, orc_en, means_en):
+    """65,536 frames in one call (256 utterances x 256): every utterance's scores equal what the
+    same utterance gets in a 1-utterance call (utterances are independent: reset history), a
+    sample is checked against the oracle, and the exact pass stays rare."""
+    n_utt, n_fr = 256, 256
+    feats = np.concatenate([synth_features(means_en, n_fr, 9000 + u) for u in range(n_utt)])
+    off = (np.arange(n_utt + 1) * n_fr).astype(np.int32)
+    big = gpu_en.score_batch(feats, off)
+    flagged, pairs = gpu_en.last_stats()
+    assert pairs == n_utt * n_fr * 126 and flagged < pairs // 100
+    assert big.shape == (n_utt * n_fr, orc_en.n_sen)
+    for u in (0, 1, 97, 255):
+        one = gpu_en.score_batch(feats[off[u]:off[u + 1]])
+        assert np.array_equal(big[off[u]:off[u + 1]], one), u
+    ref = orc_en.ptm_score_utt(feats[off[97]:off[98]])
+    assert np.array_equal(big[off[97]:off[98]], ref)
+    # checksum of checksums: rows are already best-score normalised, so every row holds a zero
+    assert (big.max(axis=1) <= 0).all() or (big.min(axis=1) == 0).all()
