@@ -469,6 +469,7 @@ med3f(float a, float b, float c)
     return __builtin_amdgcn_fmed3f(a, b, c);
 }
 
+#define SSW_REC_LDS_STRIDE 36 /* dwords per exact record in LDS (32 + 4 of padding) */
 #define SSW_EXLIST_STRIDE 132 /* [0] count, [1..] codewords the scan leaves to the exact form */
 
 #if defined(SSW_TIMELINE) || defined(SSW_TIMELINE_SEN)
@@ -504,6 +505,21 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
     const int cbf = pair / P.tile_groups;
     const int tile = (pair - cbf * P.tile_groups) * 4 + (threadIdx.x >> 6);
     const int t_base = tile * 64 * FPL;
+    /* The workgroup's four waves share the codebook: its 128 exact records (the epilogue
+     * re-evaluates 4 of them per frame) are staged in LDS once, rows padded to 36 dwords so that
+     * the per-lane row gathers spread over the banks.  From L1 those gathers ran at 64 B/clk
+     * per CU and were the epilogue's whole cost. */
+    __shared__ __align__(16) float s_rec[128 * SSW_REC_LDS_STRIDE];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(rec + (size_t)cbf * 128 * SSW_REC_FLOATS);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = i * 256 + (int)threadIdx.x; /* float4 index in the 128 x 32 table */
+            const float4 v = src[e];
+            *reinterpret_cast<float4 *>(&s_rec[(e >> 3) * SSW_REC_LDS_STRIDE + (e & 7) * 4]) = v;
+        }
+    }
+    __syncthreads();
     if (t_base >= P.n_frames)
         return;
     SSW_TL(0)
@@ -520,10 +536,9 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
     const float *rec_cbf = rec + (size_t)cbf * 128 * SSW_REC_FLOATS;
     const float *rq_cbf = recq + (size_t)cbf * 128 * SSW_REC_FLOATS;
     const float d0 = recmax[(size_t)cbf * SSW_REC_FLOATS]; /* the keys are relative to this */
-    /* touch every 128-byte line of this codebook's two record tables now, so that the scalar
-     * loads of the scan and the gathers after it find them in L2 */
-    float touch = rq_cbf[lane * SSW_REC_FLOATS] + rq_cbf[(64 + lane) * SSW_REC_FLOATS]
-        + rec_cbf[lane * SSW_REC_FLOATS] + rec_cbf[(64 + lane) * SSW_REC_FLOATS];
+    /* touch every 128-byte line of this codebook's scan records now, so that the scalar loads
+     * of the scan find them in L2 */
+    float touch = rq_cbf[lane * SSW_REC_FLOATS] + rq_cbf[(64 + lane) * SSW_REC_FLOATS];
 
     int tt[FPL];
     float x[FPL][VECLEN];
@@ -667,7 +682,7 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             c[k] = (int)(__float_as_uint(L[h][k]) & 127u);
-            const float4 *rp = reinterpret_cast<const float4 *>(rec_cbf + c[k] * SSW_REC_FLOATS);
+            const float4 *rp = reinterpret_cast<const float4 *>(&s_rec[c[k] * SSW_REC_LDS_STRIDE]);
             float buf[SSW_REC_FLOATS];
 #pragma unroll
             for (int q = 0; q < SSW_REC_FLOATS / 4; ++q) {
