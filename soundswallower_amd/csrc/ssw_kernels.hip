@@ -2605,7 +2605,8 @@ launch_senone(ssw_model_s *m, int scorer, int n_frames, const uint32_t *cw, cons
     S.slot_stride = m->slot_stride;
     S.n_quads = m->n_quads;
     /* frames per workgroup: 4 when the batch still leaves >= 2 workgroups per CU, and the
-     * prologue can give every (frame, codebook, stream) its own thread */
+     * prologue can give every (frame, codebook, stream) its own thread (measured on MI355X,
+     * en-us, 4096 frames: 1 -> 65 us, 2 -> 58 us, 4 -> 53.5 us, 8 -> 68 us) */
     int fpb = n_frames >= 4 * 512 ? 4 : 1;
     size_t lds = SSW_LOGADD_LDS + (4 * SSW_MAX_FEAT + 24 * (size_t)m->n_cbf + 16 * sizeof(int)) * fpb + 16;
     /* quads per thread: as few as a 1024-thread workgroup allows (measured on MI355X, en-us:
