@@ -17,6 +17,8 @@
 #include <soundswallower/configuration.h>
 #include <soundswallower/decoder.h>
 #include <soundswallower/err.h>
+#include <soundswallower/search_module.h>
+#include <soundswallower/state_align_search.h>
 
 #include "ssw_amd.h"
 
@@ -119,4 +121,130 @@ gpu_second_pass(decoder_t *d, alignment_t *al, int n_frames)
     ckd_free(start);
     ckd_free(dur);
     return rv;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* INTEGRATION.md section 2, vtable level: a search module decoder_alignment() can drive   */
+/* unchanged.  Replace its call                                                           */
+/*     d->align = state_align_search_init("_state_align", d->config, d->acmod, al);       */
+/* (src/decoder.c:776) by gpu_state_align_search_init(...).  The object starts with the    */
+/* reference's own state_align_search_t, because decoder_alignment reads ->frame and ->al   */
+/* through that type (src/decoder.c:747-750); start/step/finish/free forward to the GPU     */
+/* object, which buffers the feature rows and runs scoring + Viterbi + backtrace at finish. */
+/* ------------------------------------------------------------------------------------ */
+typedef struct gpu_state_align_search_s {
+    state_align_search_t sas; /* base, al, n_phones, frame are the fields others read */
+    ssw_state_align_search_t *gpu;
+} gpu_state_align_search_t;
+
+static int
+gpu_sas_start(search_module_t *search)
+{
+    gpu_state_align_search_t *g = (gpu_state_align_search_t *)search;
+    g->sas.frame = 0;
+    return ssw_state_align_search_start(g->gpu);
+}
+
+static int
+gpu_sas_step(search_module_t *search, int frame_idx)
+{
+    gpu_state_align_search_t *g = (gpu_state_align_search_t *)search;
+    mfcc_t **feat = acmod_get_frame(search_module_acmod(search), &frame_idx);
+    if (feat == NULL)
+        return -1;
+    /* feat[0] is the contiguous 39-float row of the frame (src/feat.c:386-395) */
+    if (ssw_state_align_search_step(g->gpu, feat[0], frame_idx) < 0)
+        return -1;
+    g->sas.frame = frame_idx + 1;
+    return 0;
+}
+
+static int
+gpu_sas_finish(search_module_t *search)
+{
+    gpu_state_align_search_t *g = (gpu_state_align_search_t *)search;
+    const ssw_align_entry_t *st;
+    alignment_iter_t *it;
+    int32 ns, i = 0;
+
+    if (ssw_state_align_search_finish(g->gpu) < 0) {
+        E_ERROR("%s\n", ssw_last_error()); /* the two messages of src/state_align_search.c:229-241 */
+        return -1;
+    }
+    st = ssw_state_align_search_states(g->gpu, &ns);
+    for (it = alignment_states(g->sas.al); it && i < ns; it = alignment_iter_next(it), ++i) {
+        alignment_entry_t *e = alignment_iter_get(it);
+        e->start = st[i].start;
+        e->duration = st[i].duration;
+        e->score = st[i].score;
+    }
+    alignment_propagate(g->sas.al);
+    return 0;
+}
+
+static int
+gpu_sas_reinit(search_module_t *search, dict_t *dict, dict2pid_t *d2p)
+{
+    (void)search;
+    (void)dict;
+    (void)d2p;
+    return 0; /* as state_align_search_reinit (src/state_align_search.c:270-276) */
+}
+
+static void
+gpu_sas_free(search_module_t *search)
+{
+    gpu_state_align_search_t *g = (gpu_state_align_search_t *)search;
+    search_module_base_free(search);
+    ssw_state_align_search_free(g->gpu);
+    alignment_free(g->sas.al); /* consuming semantics, as the reference */
+    ckd_free(g);
+}
+
+static searchfuncs_t gpu_sas_funcs = {
+    /* start: */ gpu_sas_start,
+    /* step: */ gpu_sas_step,
+    /* finish: */ gpu_sas_finish,
+    /* reinit: */ gpu_sas_reinit,
+    /* free: */ gpu_sas_free,
+    /* lattice: */ NULL,
+    /* hyp: */ NULL,
+    /* prob: */ NULL,
+    /* seg_iter: */ NULL,
+};
+
+search_module_t *
+gpu_state_align_search_init(const char *name, config_t *config, acmod_t *acmod, alignment_t *al)
+{
+    gpu_state_align_search_t *g = ckd_calloc(1, sizeof(*g));
+    int n = alignment_n_phones(al), i = 0;
+    int32 *ssid = ckd_calloc(n, sizeof(*ssid)), *tmatid = ckd_calloc(n, sizeof(*tmatid));
+    int32 *start = ckd_calloc(n, sizeof(*start)), *dur = ckd_calloc(n, sizeof(*dur));
+    alignment_iter_t *it;
+
+    search_module_init(search_module_base(g), &gpu_sas_funcs, PS_SEARCH_TYPE_STATE_ALIGN, name,
+                       config, acmod, al->d2p->dict, al->d2p);
+    g->sas.al = al; /* consuming semantics */
+    g->sas.n_phones = n;
+    g->sas.n_emit_state = alignment_n_states(al);
+    for (it = alignment_phones(al); it && i < n; it = alignment_iter_next(it), ++i) {
+        alignment_entry_t *e = alignment_iter_get(it);
+        ssid[i] = e->id.pid.ssid;
+        tmatid[i] = e->id.pid.tmatid;
+        start[i] = e->start;
+        dur[i] = e->duration;
+    }
+    g->gpu = ssw_state_align_search_init(gpu_model, (ssw_mgau_t *)acmod->mgau, n, ssid, tmatid,
+                                         start, dur);
+    ckd_free(ssid);
+    ckd_free(tmatid);
+    ckd_free(start);
+    ckd_free(dur);
+    if (g->gpu == NULL) {
+        E_ERROR("%s\n", ssw_last_error());
+        search_module_base_free(search_module_base(g));
+        ckd_free(g);
+        return NULL;
+    }
+    return search_module_base(g);
 }
