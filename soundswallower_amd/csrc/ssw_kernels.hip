@@ -3073,6 +3073,12 @@ struct ssw_mgau_impl {
     int16_t *d_out1;
     uint8_t *d_cb_active[2]; /* mgau_active of each history slot */
     uint8_t *d_sen_active;
+    int cb_all[2], sen_all;  /* the device copy currently says "everything active" */
+    /* pinned, device-mapped staging of the one-frame call: the kernels read the feature row from
+     * host memory and write the scores to it, so a frame costs two launches and one stream
+     * synchronise instead of four blocking copies */
+    float *h_feat1, *dh_feat1;
+    int16_t *h_out1, *dh_out1;
     /* whole-utterance cache filled by ssw_mgau_prescore */
     std::vector<int16_t> cache;
     int cache_frames;
@@ -3087,14 +3093,32 @@ static void mgau_free(ssw_mgau_t *mg);
 static ssw_mgaufuncs_t g_ptm_funcs = { "ptm", mgau_frame_eval, mgau_transform, mgau_free };
 
 static int
+mgau_alloc_pinned(ssw_mgau_impl *g)
+{
+    const ssw_host_model_t *h = g->m->h;
+    g->h_feat1 = NULL;
+    g->h_out1 = NULL;
+    g->cb_all[0] = g->cb_all[1] = g->sen_all = 0;
+    HIP_OK(hipHostMalloc((void **)&g->h_feat1, sizeof(float) * SSW_MAX_FEAT * SSW_MAX_VECLEN,
+                         hipHostMallocMapped));
+    HIP_OK(hipHostMalloc((void **)&g->h_out1, sizeof(int16_t) * (size_t)h->n_sen,
+                         hipHostMallocMapped));
+    HIP_OK(hipHostGetDevicePointer((void **)&g->dh_feat1, g->h_feat1, 0));
+    HIP_OK(hipHostGetDevicePointer((void **)&g->dh_out1, g->h_out1, 0));
+    return 0;
+}
+
+static int
 mgau_reset_device_hist(ssw_mgau_impl *g)
 {
     std::vector<uint32_t> init((size_t)g->m->n_cbf, 0x03020100u); /* cw = m */
     std::vector<uint8_t> ones((size_t)g->m->h->n_cb, 1);         /* all codebooks active */
     for (int i = 0; i < 2; ++i) {
         HIP_OK(hipMemcpy(g->d_hist_cw[i], init.data(), init.size() * 4, hipMemcpyHostToDevice));
-        if (g->d_cb_active[i] != NULL)
+        if (g->d_cb_active[i] != NULL) {
             HIP_OK(hipMemcpy(g->d_cb_active[i], ones.data(), ones.size(), hipMemcpyHostToDevice));
+            g->cb_all[i] = 1;
+        }
     }
     return 0;
 }
@@ -3140,6 +3164,7 @@ ssw_ptm_mgau_init(ssw_model_t *m)
     }
     int one[2] = { 0, 1 };
     ok = ok && hipMemcpy(g->d_utt1, one, sizeof(one), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && mgau_alloc_pinned(g) == 0;
     ok = ok && mgau_reset_device_hist(g) == 0;
     if (!ok) {
         mgau_free(&g->base);
@@ -3292,13 +3317,16 @@ mgau_frame_eval(ssw_mgau_t *mg, int16_t *senscr, uint8_t *senone_active,
 
     const int slot = frame % 2;
     if (frame >= g->base.frame_idx) {
-        HIP_OK(hipMemcpy(g->d_feat1, row, sizeof(float) * h->veclen_total, hipMemcpyHostToDevice));
-        if (compallsen)
-            cb_act.assign((size_t)h->n_cb, 1);
-        HIP_OK(hipMemcpy(g->d_cb_active[slot], cb_act.data(), (size_t)h->n_cb,
-                         hipMemcpyHostToDevice));
+        memcpy(g->h_feat1, row, sizeof(float) * h->veclen_total);
+        if (!(compallsen && g->cb_all[slot])) {
+            if (compallsen)
+                cb_act.assign((size_t)h->n_cb, 1);
+            HIP_OK(hipMemcpy(g->d_cb_active[slot], cb_act.data(), (size_t)h->n_cb,
+                             hipMemcpyHostToDevice));
+            g->cb_all[slot] = compallsen ? 1 : 0;
+        }
         ChainParams P;
-        fill_chain_params(m, P, g->d_feat1);
+        fill_chain_params(m, P, g->dh_feat1);
         P.utt_off = g->d_utt1;
         P.n_utts = 1;
         P.carry_pk = g->d_hist_cw[slot ^ 1]; /* lastf, src/ptm_mgau.c:435-441 */
@@ -3310,9 +3338,13 @@ mgau_frame_eval(ssw_mgau_t *mg, int16_t *senscr, uint8_t *senone_active,
                            dim3(256), 0, 0, P);
         HIP_OK(hipGetLastError());
     }
-    if (compallsen)
-        sen_act.assign((size_t)h->n_sen, 1);
-    HIP_OK(hipMemcpy(g->d_sen_active, sen_act.data(), (size_t)h->n_sen, hipMemcpyHostToDevice));
+    if (!(compallsen && g->sen_all)) {
+        if (compallsen)
+            sen_act.assign((size_t)h->n_sen, 1);
+        HIP_OK(hipMemcpy(g->d_sen_active, sen_act.data(), (size_t)h->n_sen,
+                         hipMemcpyHostToDevice));
+        g->sen_all = compallsen ? 1 : 0;
+    }
     {
         SenoneFrameParams F;
         F.topn_cw = g->d_hist_cw[slot];
@@ -3323,7 +3355,7 @@ mgau_frame_eval(ssw_mgau_t *mg, int16_t *senscr, uint8_t *senone_active,
         F.cb_active = g->d_cb_active[slot];
         F.sen_active = g->d_sen_active;
         F.slot_sen = m->d_slot_sen;
-        F.out = g->d_out1;
+        F.out = g->dh_out1;
         F.n_cb = h->n_cb;
         F.n_feat = h->n_feat;
         F.n_density = h->n_density;
@@ -3334,7 +3366,8 @@ mgau_frame_eval(ssw_mgau_t *mg, int16_t *senscr, uint8_t *senone_active,
                            8 * (size_t)m->n_cbf, 0, F);
         HIP_OK(hipGetLastError());
     }
-    HIP_OK(hipMemcpy(senscr, g->d_out1, sizeof(int16_t) * h->n_sen, hipMemcpyDeviceToHost));
+    HIP_OK(hipStreamSynchronize(0));
+    memcpy(senscr, g->h_out1, sizeof(int16_t) * h->n_sen);
     return 0;
 }
 
@@ -3362,6 +3395,8 @@ mgau_free(ssw_mgau_t *mg)
     (void)hipFree(g->d_utt1);
     (void)hipFree(g->d_feat1);
     (void)hipFree(g->d_out1);
+    (void)hipHostFree(g->h_feat1);
+    (void)hipHostFree(g->h_out1);
     delete g;
 }
 
