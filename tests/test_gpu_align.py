@@ -88,3 +88,53 @@ def test_other_alignment_kernels_match_oracle(gpu_en, orc_en, monkeypatch, mode)
     monkeypatch.setenv("SSW_ALIGN_KERNEL", mode)
     for n_phones, n_frames in ((64, 300), (65, 300), (150, 700), (256, 900)):
         test_align_matches_oracle(gpu_en, orc_en, n_phones, n_frames)
+
+
+def test_skip_arc_topologies_match_oracle(orc_en, oracle_mod, monkeypatch, tmp_path):
+    """Both shipped models have no skip arcs, so the skip branches of hmm_vit_eval_3st_lr
+    (src/hmm.c:496-535, including the t2 left over from the exit block) never run on them.
+    A synthetic transition_matrices file with 0->2 and 1->exit arcs in some matrices and not in
+    others exercises them in all three alignment kernels."""
+    import os
+    import struct
+
+    import soundswallower_amd as ssw
+    from tests.test_cabi_host import _write_s3
+
+    rng = np.random.default_rng(77)
+    n_tmat = int(orc_en.n_tmat)
+    tm = np.zeros((n_tmat, 3, 4), "<f4")
+    for i in range(n_tmat):
+        kind = i % 4  # 0: both skips, 1: only 0->2, 2: only 1->exit, 3: none
+        for j in range(3):
+            row = np.zeros(4)
+            row[j] = rng.uniform(0.3, 0.8)
+            row[j + 1] = rng.uniform(0.2, 0.6)
+            if j + 2 <= 3 and ((j == 0 and kind in (0, 1)) or (j == 1 and kind in (0, 2))):
+                row[j + 2] = rng.uniform(0.05, 0.5)
+            tm[i, j] = row
+    path = str(tmp_path / "transition_matrices")
+    _write_s3(path, struct.pack("<4i", n_tmat, 3, 4, tm.size) + tm.tobytes())
+    src = ssw.model_dir("en-us")
+    kw = dict(mdef=os.path.join(src, "mdef"), means=os.path.join(src, "means"),
+              sendump=os.path.join(src, "sendump"), tmat=path)
+    g = ssw.Model(variances=os.path.join(src, "variances"), **kw)
+    o = oracle_mod.Model(vars=os.path.join(src, "variances"), **kw)
+    assert np.array_equal(g.table("tp"), o.tp.reshape(-1))
+    tp = o.tp
+    assert (tp[:, 0, 2] < 255).any() and (tp[:, 0, 2] == 255).any() and (tp[:, 1, 3] < 255).any()
+    for mode in ("mw", "reg", "lds"):
+        monkeypatch.setenv("SSW_ALIGN_KERNEL", mode)
+        for n_phones, n_frames in ((6, 30), (70, 260), (150, 500)):
+            senid, tmat, _ = synth_alignment_task(o.sseq, o.phone_ssid, o.phone_tmat, o.n_ciphone,
+                                                  n_phones, 1234 + n_phones)
+            scr = _random_senscr(n_frames, o.n_sen, 55 + n_phones)
+            rv, rst, _ = o.state_align(scr, senid, tmat)
+            d = g.to_device(scr)
+            try:
+                st, status = g.align_batch(d, [0, n_frames], [0, n_phones], senid, tmat)
+            finally:
+                g.device_free(d)
+            assert (status[0] == 0) == (rv == 0), (mode, n_phones)
+            assert rv == 0
+            assert np.array_equal(st, rst), (mode, n_phones)
