@@ -88,12 +88,20 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the scoring path has no CPU fallback")
+    # SSW_BENCH_BACKEND=gloo + SSW_BENCH_DEVICE=0 let several ranks share one GPU, to exercise the
+    # multi-rank control flow on a 1-GPU box; the driver's runs use nccl (= RCCL), one GPU per rank
+    backend = os.environ.get("SSW_BENCH_BACKEND", "nccl")
+    if "SSW_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["SSW_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import soundswallower_amd as ssw
     from soundswallower_amd import _lib
@@ -137,7 +145,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
