@@ -1761,7 +1761,9 @@ viterbi_align_kernel(AlignParams P)
     }
 
     /* state_align_search_finish (state_align_search.c:215-268) */
-    __threadfence();
+    /* the token stack is read back by this workgroup only: workgroup-scope ordering (an
+     * agent-scope fence would write back and invalidate the XCD's L2 under the other
+     * utterances) */
     __syncthreads();
     if (lane == 0)
         align_backtrace(P, U, u, tok, n_states, L(A_OH, NP - 1), L(A_OS, NP - 1));
@@ -1941,7 +1943,9 @@ viterbi_align_reg_kernel(AlignParams P)
             fin_oh = __shfl(oh[w], ll, WAVE);
             fin_os = __shfl(os[w], ll, WAVE);
         }
-    __threadfence();
+    /* the token stack is read back by this workgroup only: workgroup-scope ordering (an
+     * agent-scope fence would write back and invalidate the XCD's L2 under the other
+     * utterances) */
     __syncthreads();
     if (lane == 0)
         align_backtrace(P, U, u, tok, n_states, fin_oh, fin_os);
@@ -2110,7 +2114,9 @@ viterbi_align_mw_kernel(AlignParams P)
         x_fin[0] = oh;
         x_fin[1] = os;
     }
-    __threadfence();
+    /* the token stack is read back by this workgroup only: workgroup-scope ordering (an
+     * agent-scope fence would write back and invalidate the XCD's L2 under the other
+     * utterances) */
     __syncthreads();
     if (threadIdx.x == 0)
         align_backtrace(P, U, u, tok, n_states, x_fin[0], x_fin[1]);
