@@ -905,6 +905,9 @@ ptm_senone_kernel(SenoneParams P)
 #define STL(k)
 #endif
     STL(0)
+    /* set-up, block minimum and output are short latency-bound phases that the rest of the
+     * workgroup (or its successor) waits for: let them issue ahead of other groups' main loops */
+    __builtin_amdgcn_s_setprio(2);
     /* NF = number of streams when known at compile time (0 = read it from P): with a constant
      * trip count the 12 row loads of a quad are all issued before the first log-add */
     const int n_feat = NF ? NF : P.n_feat;
@@ -979,6 +982,7 @@ ptm_senone_kernel(SenoneParams P)
     __syncthreads();
 
     STL(1)
+    __builtin_amdgcn_s_setprio(0);
     /* senone combine, src/ptm_mgau.c:342-395 */
     int asc[R][FPB][4];
     int best[FPB];
@@ -1059,6 +1063,7 @@ ptm_senone_kernel(SenoneParams P)
         }
     }
     STL(2)
+    __builtin_amdgcn_s_setprio(2);
     /* block minimum of every frame: wave minimum by DPP, one LDS word per (frame, wave), one
      * barrier, then every wave folds the partials itself */
 #pragma unroll
