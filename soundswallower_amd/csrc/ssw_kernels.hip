@@ -1433,7 +1433,16 @@ struct AlignParams {
     int n_sen, n_utts, max_phones;
 };
 
-/* hmm_vit_eval_3st_lr, src/hmm.c:482-567.  n0..n2 are the NEGATED senone scores. */
+/* hmm_vit_eval_3st_lr, src/hmm.c:482-567.  n0..n2 are the NEGATED senone scores.  Written
+ * with selects instead of the reference's nested ifs (a lone wave pays for every branch with
+ * scalar exec-mask bookkeeping); the decision tree is the same, including the t2 that the state-2
+ * block inherits from the exit block when it has no 0->2 arc of its own (:496,501-502,519-520):
+ *   exit   only if s1 + n1 > WORST:  t1 = a2 + tp23, t2 = a1 + tp13 if that arc exists else
+ *          INT_MIN;  take t1 iff t1 > t2 (history of state 2), else t2 (history of state 1)
+ *   state2 t0 = a2 + tp22, t1 = a1 + tp12, t2 = a0 + tp02 if that arc exists, else the exit
+ *          block's t2;  if t0 > t1: (t2 > t0 ? t2/h0 : t0/h2) else (t2 > t1 ? t2/h0 : t1/h1)
+ *   state1 t0 = a1 + tp11, t1 = a0 + tp01;  t0 > t1 ? t0/h1 : t1/h0
+ *   state0 a0 + tp00;  every new score clamped to WORST, best = max over them and the exit. */
 __device__ __forceinline__ int
 vit_eval_3st(int &s0, int &s1, int &s2, int &h0, int &h1, int &h2, int &os, int &oh, int n0,
              int n1, int n2, uint32_t tpa, uint32_t tpb, uint32_t tpc)
@@ -1443,71 +1452,45 @@ vit_eval_3st(int &s0, int &s1, int &s2, int &h0, int &h1, int &h2, int &os, int 
     const int tp11 = TPQ(tpb, 1), tp12 = TPQ(tpb, 2), tp13 = TPQ(tpb, 3);
     const int tp22 = TPQ(tpc, 2), tp23 = TPQ(tpc, 3);
 #undef TPQ
-    int a2 = s2 + n2, a1 = s1 + n1, a0 = s0 + n0;
-    int best = SSW_WORST_SCORE;
-    int t0, t1, t2 = INT_MIN; /* t2 is deliberately not reset between the two blocks */
+    const int a2 = s2 + n2, a1 = s1 + n1, a0 = s0 + n0;
+    const int W = SSW_WORST_SCORE;
 
-    if (a1 > SSW_WORST_SCORE) {
-        int s3;
-        t1 = a2 + tp23;
-        if (tp13 > -255)
-            t2 = a1 + tp13;
-        if (t1 > t2) {
-            s3 = t1;
-            oh = h2;
-        } else {
-            s3 = t2;
-            oh = h1;
-        }
-        if (s3 < SSW_WORST_SCORE)
-            s3 = SSW_WORST_SCORE;
-        os = s3;
-        best = s3;
-    }
-    t0 = a2 + tp22;
-    t1 = a1 + tp12;
-    if (tp02 > -255)
-        t2 = a0 + tp02;
-    int ns2;
-    if (t0 > t1) {
-        if (t2 > t0) {
-            ns2 = t2;
-            h2 = h0;
-        } else
-            ns2 = t0;
-    } else {
-        if (t2 > t1) {
-            ns2 = t2;
-            h2 = h0;
-        } else {
-            ns2 = t1;
-            h2 = h1;
-        }
-    }
-    if (ns2 < SSW_WORST_SCORE)
-        ns2 = SSW_WORST_SCORE;
-    if (ns2 > best)
-        best = ns2;
+    /* exit */
+    const bool a1_live = a1 > W;
+    const int e1 = a2 + tp23;
+    const int e2 = (a1_live && tp13 > -255) ? a1 + tp13 : INT_MIN;
+    const bool from2 = e1 > e2;
+    int s3 = from2 ? e1 : e2;
+    s3 = s3 < W ? W : s3;
+    const int oh_new = from2 ? h2 : h1;
+    os = a1_live ? s3 : os;
+    oh = a1_live ? oh_new : oh;
+    int best = a1_live ? s3 : W;
 
-    int ns1;
-    t0 = a1 + tp11;
-    t1 = a0 + tp01;
-    if (t0 > t1) {
-        ns1 = t0;
-    } else {
-        ns1 = t1;
-        h1 = h0;
-    }
-    if (ns1 < SSW_WORST_SCORE)
-        ns1 = SSW_WORST_SCORE;
-    if (ns1 > best)
-        best = ns1;
+    /* state 2 (uses h1, h2 as they were) */
+    const int t0 = a2 + tp22, t1 = a1 + tp12;
+    const int t2 = (tp02 > -255) ? a0 + tp02 : e2;
+    const bool self2 = t0 > t1;
+    const int base2 = self2 ? t0 : t1;
+    const int hb2 = self2 ? h2 : h1;
+    const bool skip2 = t2 > base2;
+    int ns2 = skip2 ? t2 : base2;
+    h2 = skip2 ? h0 : hb2;
+    ns2 = ns2 < W ? W : ns2;
+    best = ns2 > best ? ns2 : best;
 
+    /* state 1 */
+    const int u0 = a1 + tp11, u1 = a0 + tp01;
+    const bool self1 = u0 > u1;
+    int ns1 = self1 ? u0 : u1;
+    h1 = self1 ? h1 : h0;
+    ns1 = ns1 < W ? W : ns1;
+    best = ns1 > best ? ns1 : best;
+
+    /* state 0 */
     int ns0 = a0 + tp00;
-    if (ns0 < SSW_WORST_SCORE)
-        ns0 = SSW_WORST_SCORE;
-    if (ns0 > best)
-        best = ns0;
+    ns0 = ns0 < W ? W : ns0;
+    best = ns0 > best ? ns0 : best;
     s0 = ns0;
     s1 = ns1;
     s2 = ns2;
@@ -2015,35 +1998,36 @@ viterbi_align_mw_kernel(AlignParams P)
 
     int2 *tok = P.tokens + U.tok_off;
     int best_score = 0;
+    /* The frame step is written with selects rather than branches: a lone wave pays for every
+     * divergent `if` with scalar exec-mask bookkeeping, and lanes without a phone hold an inert
+     * HMM (scores WORST, frame -1) that the arithmetic leaves inert.  Only stores are masked. */
+    int2 *tkrow = tok + (real ? p * 3 : 0);
     auto frame = [&](const int t, const int cur01, const int cur2, int &fut01, int &fut2) {
         const int nf = t + 1, par = t & 1;
+        const int W = SSW_WORST_SCORE;
         fetch(t + 2, fut01, fut2);
-        const bool renorm = (best_score - 0x300000) < SSW_WORST_SCORE;
-        int bs = SSW_WORST_SCORE;
-
-        /* renormalize_hmms + evaluate_hmms + prune_hmms (state_align_search.c:57-106) */
-        if (real) {
-            if (renorm) { /* hmm_normalize, src/hmm.c:150-161 */
-                if (s0 > SSW_WORST_SCORE)
-                    s0 -= best_score;
-                if (s1 > SSW_WORST_SCORE)
-                    s1 -= best_score;
-                if (s2 > SSW_WORST_SCORE)
-                    s2 -= best_score;
-                if (os > SSW_WORST_SCORE)
-                    os -= best_score;
-            }
-            if (fr >= t) {
-                const int n0 = -(int)(int16_t)(cur01 & 0xffff);
-                const int n1 = -(cur01 >> 16);
-                const int n2 = -cur2;
-                int b = vit_eval_3st(s0, s1, s2, h0, h1, h2, os, oh, n0, n1, n2, tpa, tpb, tpc);
-                bs = b > bs ? b : bs;
-                if (nf <= ef)
-                    fr = nf;
-            }
-        }
-        bs = wave_max_dpp(bs);
+        /* renormalize_hmms (hmm_normalize, src/hmm.c:150-161) */
+        const bool renorm = (best_score - 0x300000) < W;
+        s0 = (renorm && s0 > W) ? s0 - best_score : s0;
+        s1 = (renorm && s1 > W) ? s1 - best_score : s1;
+        s2 = (renorm && s2 > W) ? s2 - best_score : s2;
+        os = (renorm && os > W) ? os - best_score : os;
+        /* evaluate_hmms + prune_hmms (state_align_search.c:57-106): evaluated for every lane,
+         * kept for the phones that are active in this frame */
+        const bool active = fr >= t;
+        int e0 = s0, e1 = s1, e2 = s2, g0 = h0, g1 = h1, g2 = h2, eos = os, eoh = oh;
+        const int b = vit_eval_3st(e0, e1, e2, g0, g1, g2, eos, eoh,
+                                   -(int)(int16_t)(cur01 & 0xffff), -(cur01 >> 16), -cur2, tpa,
+                                   tpb, tpc);
+        s0 = active ? e0 : s0;
+        s1 = active ? e1 : s1;
+        s2 = active ? e2 : s2;
+        h1 = active ? g1 : h1;
+        h2 = active ? g2 : h2;
+        os = active ? eos : os;
+        oh = active ? eoh : oh;
+        fr = (active && nf <= ef) ? nf : fr;
+        int bs = wave_max_dpp(active ? b : W);
         if (lane == 0) {
             x_bs[par][w] = bs;
             x_fr0[par][w] = fr;
@@ -2054,7 +2038,7 @@ viterbi_align_mw_kernel(AlignParams P)
             x_oh63[par][w] = oh;
         }
         lds_barrier();
-        best_score = SSW_WORST_SCORE;
+        best_score = W;
         for (int k = 0; k < nw; ++k) {
             int v = x_bs[par][k];
             best_score = v > best_score ? v : best_score;
@@ -2065,7 +2049,7 @@ viterbi_align_mw_kernel(AlignParams P)
         const int es0 = w + 1 < nw ? x_s00[par][w + 1] : 0;
         const int nfr = lane_from_next(fr, efr);
         const int ns0 = lane_from_next(s0, es0);
-        const bool a_bit = real && fr == nf;
+        const bool a_bit = fr == nf; /* lanes without a phone keep frame -1 */
         const bool c_bit = p + 1 < NP && nf >= sf_next && (nfr < t || os > ns0);
         const unsigned long long Am = __ballot(a_bit), Cm = __ballot(c_bit);
         if (lane == 0) {
@@ -2082,29 +2066,26 @@ viterbi_align_mw_kernel(AlignParams P)
         }
         const unsigned long long X = Cm, Y = Am & Cm;
         const unsigned long long E = (X + Y + cin) ^ X ^ Y; /* bit i: phone (w*64+i) is entered */
-        const bool entered = (E >> lane) & 1ull;
+        const bool entered = real && ((E >> lane) & 1ull);
         const int src_os = lane_from_prev(os, w > 0 ? x_os63[par][w > 0 ? w - 1 : 0] : 0);
         const int src_oh = lane_from_prev(oh, w > 0 ? x_oh63[par][w > 0 ? w - 1 : 0] : 0);
-        if (real) { /* record_transitions (:149-175) */
-            if (entered) { /* hmm_enter, src/hmm.c:142-148 */
-                s0 = src_os;
-                h0 = src_oh;
-                fr = nf;
-            }
-            int2 k0 = make_int2(-1, -1), k1 = k0, k2 = k0;
-            if (fr >= t) {
-                k0 = make_int2(h0, s0);
-                k1 = make_int2(h1, s1);
-                k2 = make_int2(h2, s2);
-                h0 = p * 3;
-                h1 = p * 3 + 1;
-                h2 = p * 3 + 2;
-            }
-            int2 *tkrow = tok + (size_t)t * n_states;
-            tkrow[p * 3] = k0;
-            tkrow[p * 3 + 1] = k1;
-            tkrow[p * 3 + 2] = k2;
+        /* hmm_enter (src/hmm.c:142-148), then record_transitions (:149-175) */
+        s0 = entered ? src_os : s0;
+        h0 = entered ? src_oh : h0;
+        fr = entered ? nf : fr;
+        const bool rec = fr >= t;
+        const int2 k0 = make_int2(rec ? h0 : -1, rec ? s0 : -1);
+        const int2 k1 = make_int2(rec ? h1 : -1, rec ? s1 : -1);
+        const int2 k2 = make_int2(rec ? h2 : -1, rec ? s2 : -1);
+        h0 = rec ? p * 3 : h0;
+        h1 = rec ? p * 3 + 1 : h1;
+        h2 = rec ? p * 3 + 2 : h2;
+        if (real) {
+            tkrow[0] = k0;
+            tkrow[1] = k1;
+            tkrow[2] = k2;
         }
+        tkrow += n_states;
     };
     for (int t = 0; t < U.n_frames; t += 3) { /* the same trip count in every wave: barriers */
         frame(t, a01, a2, c01, c2);
