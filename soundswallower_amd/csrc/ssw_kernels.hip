@@ -2751,9 +2751,7 @@ ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_fram
         HIP_OK(hipGetLastError());
         /* one work item per wave; the list is normally far shorter than the grid */
         int64_t fb = pairs / 64 + 1;
-        int fix_blocks = (int)(fb > 2048 ? 2048 : fb);
-        if (getenv("SSW_FIX_BLOCKS"))
-            fix_blocks = atoi(getenv("SSW_FIX_BLOCKS"));
+        const int fix_blocks = (int)(fb > 2048 ? 2048 : fb);
         if (ms)
             hipLaunchKernelGGL((ms_topn_fixup_kernel<13, 2, 4>), dim3(fix_blocks), dim3(64), 0,
                                st, P, m->d_nfixed);
