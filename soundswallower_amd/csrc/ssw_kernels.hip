@@ -725,9 +725,9 @@ ptm_topn_frames_kernel(const float *__restrict__ rec, const float *__restrict__ 
         uint32_t kb = __float_as_uint(L[h][4]);
         float ub = __uint_as_float((kb & 0x80000000u) ? (kb & ~127u) : (kb | 127u));
         /* the scan's keys are upper bounds, relative to d0, up to a term proportional to
-         * their own size: v + 104 * 2^-24 |v| is increasing in v, so the
-         * 5th key bounds every density outside the four; back to absolute, rounded up */
-        ub = ub + __builtin_fabsf(ub) * 6.198883056640625e-06f;
+         * their own size: v + 104 * 2^-24 |v| + 0.001 is increasing in v,
+         * so the 5th key bounds every density outside the four; back to absolute, rounded up */
+        ub = ub + __builtin_fabsf(ub) * 6.198883056640625e-06f + 1.0e-3f;
         ub = ub + d0;
         ub = ub + __builtin_fabsf(ub) * 2.384185791015625e-07f;
         bool proven;
@@ -2191,10 +2191,12 @@ upload_model(ssw_model_s *m)
          * with 26 fused multiply-adds.  With u = 2^-24, S = sum var (x - mean)^2 and
          * M = |det - d0| + R + sum |a x| + sum |b| x^2 <= |det - d0| + 6 R + 3 S
          * (Cauchy-Schwarz), the form is within 27 u M of the real number and the reference's
-         * fp32 value within 13 u |det| + 16 u S of it; with S <= |det - d0| + |value - d0| that
-         * is u (124 |det - d0| + 162 R + 13 |det|) -- folded into c as `bias`, so the key is an
-         * upper bound -- plus 97 u |value - d0|, which the kernel adds to the one key it uses as
-         * a bound.  Densities whose bias would exceed 4 score units (floored variances far from
+         * fp32 value within 13 u |det| + 17 u S of it (13 subtractions whose partial sums lie
+         * between det and the result; (1+u)^4 on every product); with
+         * S <= |det - d0| + |value - d0| that is u (125 |det - d0| + 162 R + 13 |det|) -- folded
+         * into c as `bias` with a few per cent of slack, so the key is an upper bound -- plus
+         * 98 u |value - d0|, which the kernel adds (104 u |key| + 0.001: |value| and |key| differ
+         * by at most the bias) to the one key it uses as a bound.  Densities whose bias would exceed 4 score units (floored variances far from
          * the origin) get an inert scan record and go on the codebook's exact-form list: the
          * kernel evaluates them the reference's way after the scan. */
         std::vector<float> rq(rec.size(), 0.0f), rmax((size_t)ncbf * SSW_REC_FLOATS, 0.0f);
@@ -2219,7 +2221,7 @@ upload_model(ssw_model_s *m)
                     R += fabs(var) * mean * mean;
                     finite = finite && std::isfinite(mean) && std::isfinite(var) && var >= 0.0;
                 }
-                const double bias = 1.05 * u24 * (124.0 * fabs(delta) + 162.0 * R + 13.0 * fabs(det));
+                const double bias = 1.05 * u24 * (126.0 * fabs(delta) + 164.0 * R + 14.0 * fabs(det));
                 if (!finite || !(bias <= 4.0)) {
                     uint32_t *xl = exl.data() + (size_t)cbf * SSW_EXLIST_STRIDE;
                     xl[1 + xl[0]++] = (uint32_t)d;
