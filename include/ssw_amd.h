@@ -215,6 +215,21 @@ int32_t ssw_alignment_populate(const ssw_model_t *m, const ssw_dict_t *d, int32_
                                int32_t *tmatid, int32_t *cipid, int32_t *parent,
                                int32_t *ph_start, int32_t *ph_duration);
 
+/* decoder_result_json(d, utt_start, align_level >= 1) (src/decoder.c:1339-1593): the one-line
+ * JSON the reference prints for an alignment, {"b","d","p","t","w":[...]} with b/d in seconds
+ * (frames / frate) and p = logmath_exp(score).  hyp / hyp_logprob are the first pass's text
+ * and posterior (decoder_hyp / decoder_prob: not part of this path, passed through).  Phones
+ * must be grouped by ascending parent word, as ssw_alignment_populate writes them; pass
+ * state_senid / state_al (3 per phone) for align_level 2, NULL for level 1.  Writes at most
+ * out_len bytes (NUL-terminated) and returns the full length, snprintf-style; -1 on bad
+ * arguments. */
+int32_t ssw_alignment_json(const ssw_model_t *m, const char *hyp, int32_t hyp_logprob,
+                           double utt_start, int32_t frate, int32_t n_frames, int32_t n_words,
+                           const char *const *words, const ssw_align_entry_t *word_al,
+                           int32_t n_phones, const int32_t *cipid, const int32_t *parent,
+                           const ssw_align_entry_t *phone_al, const uint16_t *state_senid,
+                           const ssw_align_entry_t *state_al, char *out, int32_t out_len);
+
 /* ------------------------------------------------------------------------------------ */
 /* Dynamic features on the device: feat_s2mfc2feat_live for whole    */
 /* utterances with feat = 1s_c_d_dd, cmn = batch ("current"), no varnorm / agc / lda       */

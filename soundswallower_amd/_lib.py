@@ -118,6 +118,9 @@ def lib() -> C.CDLL:
     L.ssw_ciphone_name.argtypes = [vp, i32]
     L.ssw_phone_id_nearest.restype = i32
     L.ssw_phone_id_nearest.argtypes = [vp, i32, i32, i32, i32]
+    L.ssw_alignment_json.restype = i32
+    L.ssw_alignment_json.argtypes = [vp, C.c_char_p, i32, C.c_double, i32, i32, i32, vp, vp, i32, vp,
+                                     vp, vp, vp, vp, C.c_char_p, i32]
     L.ssw_alignment_populate.restype = i32
     L.ssw_alignment_populate.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.ssw_feat_batch.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]

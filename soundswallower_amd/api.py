@@ -368,6 +368,27 @@ class Lexicon:
         _check(k, "ssw_alignment_populate")
         return {key: v[:k].copy() for key, v in out.items()}
 
+    def alignment_json(self, hyp, words, word_al, cipid, parent, phone_al, n_frames,
+                       state_senid=None, state_al=None, hyp_logprob=0, utt_start=0.0, frate=100):
+        """decoder_result_json at align_level 1 (or 2 with the state level): the reference's
+        one-line JSON for an alignment.  *_al: int32 [n][3] (start, duration, score)."""
+        n = len(words)
+        arr = (C.c_char_p * n)(*[w.encode() for w in words])
+        wa = np.ascontiguousarray(word_al, np.int32).reshape(-1, 3)
+        pa = np.ascontiguousarray(phone_al, np.int32).reshape(-1, 3)
+        ci = np.ascontiguousarray(cipid, np.int32)
+        par = np.ascontiguousarray(parent, np.int32)
+        sid = None if state_senid is None else np.ascontiguousarray(state_senid, np.uint16)
+        sa = None if state_al is None else np.ascontiguousarray(state_al, np.int32).reshape(-1, 3)
+        args = (self.model._m, hyp.encode(), int(hyp_logprob), float(utt_start), int(frate),
+                int(n_frames), n, arr, _ptr(wa), len(ci), _ptr(ci), _ptr(par), _ptr(pa), _ptr(sid),
+                _ptr(sa))
+        need = self._L.ssw_alignment_json(*args, None, 0)
+        _check(need, "ssw_alignment_json")
+        buf = C.create_string_buffer(need + 1)
+        _check(self._L.ssw_alignment_json(*args, buf, need + 1), "ssw_alignment_json")
+        return buf.value.decode()
+
     def free(self):
         if getattr(self, "_d", None):
             self._L.ssw_dict_free(self._d)

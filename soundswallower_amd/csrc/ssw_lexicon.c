@@ -13,6 +13,7 @@
 #include "ssw_internal.h"
 
 #include <ctype.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -341,4 +342,105 @@ ssw_ciphone_name(const ssw_model_t *m, int32_t ci)
     if (h->ciname == NULL || ci < 0 || ci >= h->n_ciphone)
         return NULL;
     return h->ciname[ci];
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* decoder_result_json at align_level >= 1 (src/decoder.c:1339-1593): one line,           */
+/*   {"b":..,"d":..,"p":..,"t":"<hyp>","w":[ word objects ]}\n                            */
+/* every object {"b":%.3f,"d":%.3f,"p":%.3f,"t":"%s"} with b = utt_start + start / frate,   */
+/* d = duration / frate, p = logmath_exp(score) = base^score (src/logmath.c:292-295); words */
+/* carry their phones in "w", phones their states (named by senone id) when state entries   */
+/* are given (align_level 2).                                                              */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    char *out;
+    size_t cap, len;
+} json_buf_t;
+
+static void
+jb_put(json_buf_t *b, const char *s, size_t n)
+{
+    if (b->out != NULL && b->len < b->cap) {
+        size_t room = b->cap - b->len - 1;
+        memcpy(b->out + b->len, s, n < room ? n : room);
+    }
+    b->len += n;
+}
+
+static void
+jb_obj(json_buf_t *b, double base, double utt_start, int frate, const ssw_align_entry_t *e,
+       const char *name)
+{
+    char tmp[96];
+    const double st = utt_start + (double)e->start / frate;
+    const double dur = (double)e->duration / frate;
+    const double prob = pow(base, (double)e->score);
+    int n = snprintf(tmp, sizeof(tmp), "{\"b\":%.3f,\"d\":%.3f,\"p\":%.3f,\"t\":\"", st, dur, prob);
+    jb_put(b, tmp, (size_t)n);
+    jb_put(b, name, strlen(name));
+    jb_put(b, "\"", 1);
+}
+
+int32_t
+ssw_alignment_json(const ssw_model_t *m, const char *hyp, int32_t hyp_logprob, double utt_start,
+                   int32_t frate, int32_t n_frames, int32_t n_words, const char *const *words,
+                   const ssw_align_entry_t *word_al, int32_t n_phones, const int32_t *cipid,
+                   const int32_t *parent, const ssw_align_entry_t *phone_al,
+                   const uint16_t *state_senid, const ssw_align_entry_t *state_al, char *out,
+                   int32_t out_len)
+{
+    const ssw_host_model_t *h = ssw_model_host(m);
+    const double base = h->cfg.logbase;
+    json_buf_t b = { out, out_len > 0 ? (size_t)out_len : 0, 0 };
+    ssw_align_entry_t top;
+    int32_t w, p = 0;
+
+    if (frate <= 0 || n_words < 0 || n_phones < 0 || (n_words > 0 && (words == NULL || word_al == NULL))
+        || (n_phones > 0 && (cipid == NULL || parent == NULL || phone_al == NULL))
+        || (state_senid == NULL) != (state_al == NULL)) {
+        ssw_set_error("ssw_alignment_json: inconsistent arguments");
+        return -1;
+    }
+    top.start = 0;
+    top.duration = n_frames;
+    top.score = hyp_logprob;
+    jb_obj(&b, base, utt_start, frate, &top, hyp ? hyp : "");
+    jb_put(&b, ",\"w\":[", 6);
+    for (w = 0; w < n_words; ++w) {
+        int first = 1;
+        if (w > 0)
+            jb_put(&b, ",", 1);
+        jb_obj(&b, base, utt_start, frate, &word_al[w], words[w] ? words[w] : "");
+        jb_put(&b, ",\"w\":[", 6);
+        for (; p < n_phones && parent[p] == w; ++p) {
+            const char *nm = ssw_ciphone_name(m, cipid[p]);
+            if (!first)
+                jb_put(&b, ",", 1);
+            first = 0;
+            jb_obj(&b, base, utt_start, frate, &phone_al[p], nm ? nm : "");
+            if (state_al != NULL) {
+                int k;
+                jb_put(&b, ",\"w\":[", 6);
+                for (k = 0; k < h->n_emit_state; ++k) {
+                    char nm2[16];
+                    snprintf(nm2, sizeof(nm2), "%u", (unsigned)state_senid[p * h->n_emit_state + k]);
+                    if (k > 0)
+                        jb_put(&b, ",", 1);
+                    jb_obj(&b, base, utt_start, frate, &state_al[p * h->n_emit_state + k], nm2);
+                    jb_put(&b, "}", 1);
+                }
+                jb_put(&b, "]", 1);
+            }
+            jb_put(&b, "}", 1);
+        }
+        jb_put(&b, "]}", 2);
+    }
+    if (p != n_phones) {
+        ssw_set_error("ssw_alignment_json: phones are not grouped by ascending parent word");
+        return -1;
+    }
+    jb_put(&b, "]}\n", 3);
+    if (b.out != NULL && b.cap > 0)
+        b.out[b.len < b.cap ? b.len : b.cap - 1] = '\0';
+    return (int32_t)b.len;
 }

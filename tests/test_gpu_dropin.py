@@ -240,6 +240,14 @@ def test_goforward_from_words_with_product_glue(gpu_en, oracle_mod):
     # history does not change any senone score on this utterance
     assert [(int(a), int(b)) for a, b, _ in ph] == [(r[1], r[2]) for r in ref]
     assert [int(c) for _, _, c in ph] == [r[3] for r in ref]
+    # ... and printed the reference's way it is the reference's line (decoder_result_json,
+    # align_level 1, as recorded in SURVEY Appendix C)
+    from tests.test_lexicon_host import REF_JSON_PREFIX
+    words = [w for (w, _, _, _) in REF_WORDS]
+    word_al = gpu_en.propagate(ph, rows["parent"], len(words))
+    line = lex.alignment_json("go forward ten meters", words, word_al, rows["cipid"],
+                              rows["parent"], ph, n_frames=279)  # decoder_n_frames, Appendix C
+    assert line.startswith(REF_JSON_PREFIX)
     s.free()
     g.free()
     lex.free()
