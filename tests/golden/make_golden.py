@@ -59,8 +59,22 @@ def config3(n_utts=4, n_frames=1000, n_phones=150):
     return res
 
 
+def tables():
+    """SURVEY 8(c) fixture 2: hashes of the post-load tables (load-time doubles go through libm,
+    so the tables are data: a loader on another box must reproduce these bytes)."""
+    out = {}
+    for name in ("en-us", "fr-fr"):
+        m = O.Model(os.path.join(MODEL, name))
+        out[name] = {"mean": crc(m.mean), "var": crc(m.var), "det": crc(m.det),
+                     "ptm_mixw": crc(m.ptm_mixw), "tp": crc(m.tp), "sseq": crc(m.sseq),
+                     "sen2cimap": crc(m.sen2cimap), "phone_ssid": crc(m.phone_ssid),
+                     "logadd8": crc(m.logadd_table_8b.astype(np.uint8)),
+                     "logadd_main": crc(m.logadd_table.astype(np.uint16))}
+    return out
+
+
 if __name__ == "__main__":
-    g = {"config2_en_us_ptm": config2(), "config3_align": config3()}
+    g = {"config2_en_us_ptm": config2(), "config3_align": config3(), "tables": tables()}
     with open(os.path.join(ROOT, "tests", "golden", "synthetic_oracle.json"), "w") as fh:
         json.dump(g, fh, indent=1)
     print(json.dumps(g)[:400])

@@ -76,3 +76,19 @@ def test_gpu_matches_golden_config3_alignment(golden, gpu_en, orc_en, means_en):
         assert crc(scr[u * 1000:(u + 1) * 1000]) == g["senscr_crc"]
         assert (status[u] == 0) == (g["rv"] == 0)
         assert crc(st[u * 450:(u + 1) * 450]) == g["states_crc"]
+
+
+@pytest.mark.parametrize("name", ["en-us", "fr-fr"])
+def test_loader_tables_match_committed_hashes(golden, name):
+    """The product's host loaders (C, no GPU needed) reproduce the committed table bytes: means,
+    precomputed variances and determinants (libm at load time), mixture weights, transition
+    matrices, senone sequences, both log-add tables' 8-bit half."""
+    import soundswallower_amd as ssw
+    g = golden["tables"][name]
+    m = ssw.Model(ssw.model_dir(name), config={"device": -2})
+    got = {"mean": crc(m.table("mean")), "var": crc(m.table("var")), "det": crc(m.table("det")),
+           "ptm_mixw": crc(m.table("ptm_mixw")), "tp": crc(m.table("tp")),
+           "sseq": crc(m.table("sseq")), "sen2cimap": crc(m.table("sen2cb")),
+           "phone_ssid": crc(m.table("phone_ssid")), "logadd8": crc(m.table("logadd8"))}
+    for k, v in got.items():
+        assert v == g[k], k
