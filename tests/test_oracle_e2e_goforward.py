@@ -149,3 +149,22 @@ def test_goforward_alignment_matches_reference_output(oracle_mod, orc_en):
     words = [(int(ph[parent == w, 0][0]), int(ph[parent == w, 1].sum()), int(ph[parent == w, 2].sum()))
              for w in range(len(REF_WORDS))]
     assert words == [(s, d, sc) for (_, s, d, sc) in REF_WORDS]
+
+
+def test_history_sensitivity_of_goforward(oracle_mod, orc_en):
+    """SURVEY 8(c) fixture 4: on goforward the survey found exactly one frame whose PTM scores
+    depend on the carried top-N history (sequential scoring differs from scoring the same
+    frame from the reset history).  The restatement shows the same count, and the GPU tests
+    check both semantics against it."""
+    feats = goforward_features(oracle_mod)
+    orc_en.ptm_reset()
+    seq = orc_en.ptm_score_utt(feats)                  # history carried frame to frame
+    differ = []
+    for t in range(len(feats)):
+        orc_en.ptm_reset()
+        orc_en.ptm_set_frame_idx(0)
+        fresh = orc_en.ptm_frame_eval(feats[t], 0)
+        if not np.array_equal(fresh, seq[t]):
+            differ.append(t)
+    orc_en.ptm_reset()
+    assert len(differ) == 1, differ
