@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Randomised parity soak: GPU PTM scoring (through the C ABI) against the CPU oracle on many
+batches with varied feature statistics, top-N codeword order included.  Not part of the test
+suite (minutes of oracle time); prints one JSON line.  The oracle is used as the checker only."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import soundswallower_amd as ssw  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from soundswallower_amd.synth import read_raw_means, synth_features  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--model", default="en-us")
+    a = ap.parse_args()
+    mdir = ssw.model_dir(a.model)
+    g, o = ssw.Model(mdir), O.Model(mdir)
+    means = read_raw_means(mdir)
+    rng = np.random.default_rng(20261002)
+    t0 = time.time()
+    n_frames = n_batches = bad_rows = bad_topn = flagged = pairs = 0
+    kinds = {}
+    while time.time() - t0 < a.seconds:
+        kind = ["synthetic", "scaled", "gauss", "interp", "quantised", "mixed"][n_batches % 6]
+        lens = rng.integers(1, 400, size=int(rng.integers(1, 6))).tolist()
+        n = int(sum(lens))
+        base = synth_features(means, n, int(rng.integers(1, 2**31)))
+        if kind == "scaled":
+            feats = base * np.float32(rng.choice([0.1, 0.5, 2.0, 5.0, 20.0]))
+        elif kind == "gauss":
+            feats = rng.normal(0, rng.choice([0.3, 1.0, 3.0]), size=base.shape).astype(np.float32)
+        elif kind == "interp":
+            t = np.linspace(0, 1, n, dtype=np.float32)[:, None]
+            feats = (base[:1] * (1 - t) + base[-1:] * t).astype(np.float32)
+        elif kind == "quantised":
+            feats = (np.round(base * 4) / 4).astype(np.float32)   # provokes exact ties
+        elif kind == "mixed":
+            feats = base.copy()
+            feats[::3] = np.roll(base, 1, axis=0)[::3]
+            feats[::7] = 0
+        else:
+            feats = base
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        got = g.score_batch(feats, off)
+        f, p = g.last_stats()
+        gcw, _ = g.last_topn(n)
+        for u in range(len(lens)):
+            ref, rcw, _ = o.ptm_score_utt(feats[off[u]:off[u + 1]], want_topn=True)
+            bad_rows += int((got[off[u]:off[u + 1]] != ref).any(axis=1).sum())
+            bad_topn += int((gcw[off[u]:off[u + 1]].astype(np.int32) != rcw).any(axis=(1, 2, 3)).sum())
+        n_frames += n
+        n_batches += 1
+        flagged += f
+        pairs += p
+        kinds[kind] = kinds.get(kind, 0) + n
+    print(json.dumps({"model": a.model, "batches": n_batches, "frames": n_frames,
+                      "frames_by_kind": kinds, "rows_differing": bad_rows,
+                      "frames_with_topn_order_differing": bad_topn,
+                      "exact_pass_share": flagged / max(pairs, 1),
+                      "seconds": round(time.time() - t0, 1)}))
+    sys.exit(1 if bad_rows or bad_topn else 0)
+
+
+if __name__ == "__main__":
+    main()
