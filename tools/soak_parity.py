@@ -17,11 +17,70 @@ from oracle import oracle as O  # noqa: E402
 from soundswallower_amd.synth import read_raw_means, synth_features  # noqa: E402
 
 
+def soak_align(a):
+    """Random forced-alignment problems (ragged batches, random windows, all three kernels)."""
+    from soundswallower_amd.synth import lcg_uniform, synth_alignment_task
+    mdir = ssw.model_dir(a.model)
+    g, o = ssw.Model(mdir), O.Model(mdir)
+    rng = np.random.default_rng(77)
+    t0 = time.time()
+    n_utts = n_fail = bad = n_frames = 0
+    while time.time() - t0 < a.seconds:
+        mode = ["mw", "reg", "lds"][n_utts % 3]
+        os.environ["SSW_ALIGN_KERNEL"] = mode
+        k = int(rng.integers(1, 7))
+        n_ph = rng.integers(1, 300, size=k).tolist()
+        n_fr = [int(p * rng.integers(2, 6) + rng.integers(0, 9)) for p in n_ph]
+        frame_off = np.concatenate([[0], np.cumsum(n_fr)]).astype(np.int32)
+        phone_off = np.concatenate([[0], np.cumsum(n_ph)]).astype(np.int32)
+        seed = int(rng.integers(1, 2**31))
+        u = lcg_uniform(seed, int(frame_off[-1]) * o.n_sen).reshape(-1, o.n_sen)
+        scr = np.floor(u * rng.choice([60, 600, 6000])).astype(np.int16)
+        senid, tmat, sf, ef = [], [], [], []
+        for i, (p, f) in enumerate(zip(n_ph, n_fr)):
+            s_, t_, _ = synth_alignment_task(o.sseq, o.phone_ssid, o.phone_tmat, o.n_ciphone, p,
+                                             seed % 100000 + i)
+            senid.append(s_)
+            tmat.append(t_)
+            lo = np.zeros(p, np.int32)
+            hi = np.full(p, 2**31 - 1, np.int32)
+            if rng.random() < 0.5:
+                mid = (np.arange(p) * f) // p
+                slack = int(rng.integers(0, 12))
+                lo = np.maximum(mid - slack, 0).astype(np.int32)
+                hi = np.minimum(mid + f // p + slack + 1, f).astype(np.int32)
+            sf.append(lo)
+            ef.append(hi)
+        senid, tmat = np.concatenate(senid), np.concatenate(tmat)
+        sf, ef = np.concatenate(sf), np.concatenate(ef)
+        d = g.to_device(scr)
+        st, status = g.align_batch(d, frame_off, phone_off, senid, tmat, sf=sf, ef=ef)
+        g.device_free(d)
+        for i in range(k):
+            sl = slice(phone_off[i], phone_off[i + 1])
+            rv, rst, _ = o.state_align(scr[frame_off[i]:frame_off[i + 1]], senid[sl], tmat[sl],
+                                       sf=sf[sl], ef=ef[sl])
+            if (status[i] == 0) != (rv == 0):
+                bad += 1
+            elif rv == 0 and not np.array_equal(st[phone_off[i] * 3:phone_off[i + 1] * 3], rst):
+                bad += 1
+            n_fail += rv != 0
+            n_utts += 1
+            n_frames += n_fr[i]
+    print(json.dumps({"mode": "align", "utterances": n_utts, "frames": n_frames,
+                      "utterances_without_a_path": int(n_fail), "utterances_differing": bad,
+                      "seconds": round(time.time() - t0, 1)}))
+    sys.exit(1 if bad else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--model", default="en-us")
+    ap.add_argument("--mode", default="ptm", choices=["ptm", "align"])
     a = ap.parse_args()
+    if a.mode == "align":
+        return soak_align(a)
     mdir = ssw.model_dir(a.model)
     g, o = ssw.Model(mdir), O.Model(mdir)
     means = read_raw_means(mdir)
