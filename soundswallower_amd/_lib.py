@@ -52,7 +52,7 @@ class SswMgau(C.Structure):
 def build(force: bool = False) -> str:
     """Compile libssw_amd.so for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
-            if f.endswith((".c", ".hip", ".h"))] + [HEADER]
+            if f.endswith((".c", ".hip", ".h", ".inc"))] + [HEADER]
     stale = (not os.path.exists(LIB_PATH)
              or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))
     if force or stale:
