@@ -203,7 +203,8 @@ def main():
         "config": {"workload": f"PTM senone scoring, {args.model}, {args.utts} utterances x "
                                f"{UTT_FRAMES} frames = {n_frames} frames per GPU per step, "
                                f"39-dim features resident in HBM, compallsen=yes, topn=4",
-                   "n_sen": model.n_sen, "n_cb": model.n_cb, "parallelism": f"utt-shard x{world}"},
+                   "senones": model.n_sen, "codebooks": model.n_cb,
+                   "parallelism": f"utt-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "PTM path of one step: ptm_topn_frames + ptm_topn_fixup + ptm_senone",
