@@ -77,12 +77,31 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--model", default="en-us")
-    ap.add_argument("--mode", default="ptm", choices=["ptm", "align"])
+    ap.add_argument("--mode", default="ptm", choices=["ptm", "ms", "align"])
     a = ap.parse_args()
     if a.mode == "align":
         return soak_align(a)
     mdir = ssw.model_dir(a.model)
-    g, o = ssw.Model(mdir), O.Model(mdir)
+    if a.mode == "ms":
+        # the shipped models carry a sendump only: synthesise the mixture_weights file the ms
+        # scorer reads (pdf = 1.0001^-(q*1024)), as tools/bench_ms.py does
+        import struct
+        import tempfile
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from bench_ms import write_s3
+        tables = ssw.Model(mdir, config={"device": -2})
+        q = tables.table("ptm_mixw").reshape(tables.n_feat, tables.n_density, tables.n_sen)
+        pdf = np.ascontiguousarray(np.power(1.0001, -(q.astype(np.float64) * 1024.0))
+                                   .transpose(2, 0, 1), dtype="<f4")
+        mixw = os.path.join(tempfile.mkdtemp(), "mixture_weights")
+        write_s3(mixw, struct.pack("<4i", pdf.shape[0], pdf.shape[1], pdf.shape[2], pdf.size)
+                 + pdf.tobytes())
+        kw = dict(mdef=os.path.join(mdir, "mdef"), means=os.path.join(mdir, "means"),
+                  tmat=os.path.join(mdir, "transition_matrices"), mixw=mixw)
+        g = ssw.Model(variances=os.path.join(mdir, "variances"), **kw)
+        o = O.Model(vars=os.path.join(mdir, "variances"), **kw)
+    else:
+        g, o = ssw.Model(mdir), O.Model(mdir)
     means = read_raw_means(mdir)
     rng = np.random.default_rng(20261002)
     t0 = time.time()
@@ -109,19 +128,27 @@ def main():
         else:
             feats = base
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-        got = g.score_batch(feats, off)
-        f, p = g.last_stats()
-        gcw, _ = g.last_topn(n)
-        for u in range(len(lens)):
-            ref, rcw, _ = o.ptm_score_utt(feats[off[u]:off[u + 1]], want_topn=True)
-            bad_rows += int((got[off[u]:off[u + 1]] != ref).any(axis=1).sum())
-            bad_topn += int((gcw[off[u]:off[u + 1]].astype(np.int32) != rcw).any(axis=(1, 2, 3)).sum())
+        if a.mode == "ms":
+            got = g.score_batch(feats, off, scorer=ssw.SCORER_MS)
+            f, p = g.last_stats()
+            for u in range(len(lens)):
+                ref = o.ms_score_utt(feats[off[u]:off[u + 1]])
+                bad_rows += int((got[off[u]:off[u + 1]] != ref).any(axis=1).sum())
+        else:
+            got = g.score_batch(feats, off)
+            f, p = g.last_stats()
+            gcw, _ = g.last_topn(n)
+            for u in range(len(lens)):
+                ref, rcw, _ = o.ptm_score_utt(feats[off[u]:off[u + 1]], want_topn=True)
+                bad_rows += int((got[off[u]:off[u + 1]] != ref).any(axis=1).sum())
+                bad_topn += int((gcw[off[u]:off[u + 1]].astype(np.int32) != rcw)
+                                .any(axis=(1, 2, 3)).sum())
         n_frames += n
         n_batches += 1
         flagged += f
         pairs += p
         kinds[kind] = kinds.get(kind, 0) + n
-    print(json.dumps({"model": a.model, "batches": n_batches, "frames": n_frames,
+    print(json.dumps({"mode": a.mode, "model": a.model, "batches": n_batches, "frames": n_frames,
                       "frames_by_kind": kinds, "rows_differing": bad_rows,
                       "frames_with_topn_order_differing": bad_topn,
                       "exact_pass_share": flagged / max(pairs, 1),
