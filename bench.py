@@ -32,7 +32,7 @@ UTT_FRAMES = 256
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, MI355X_MICROARCH.md
 N_SIMD = 1024                   # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9
-PMC_FILE = "r01_k_pmc.json"    # committed rocprofv3 --pmc measurement of this exact step
+PMC_FILE = "r01_l_pmc.json"    # committed rocprofv3 --pmc measurement of this exact step
 
 
 def algorithmic_bytes(n_sen, n_feat, topn, n_cb, n_density, veclen_total, batch):
