@@ -122,3 +122,41 @@ def test_ptm_large_batch_is_size_independent(gpu_en, orc_en, means_en):
     assert np.array_equal(big[off[97]:off[98]], ref)
     # checksum of checksums: rows are already best-score normalised, so every row holds a zero
     assert (big.max(axis=1) <= 0).all() or (big.min(axis=1) == 0).all()
+
+
+@pytest.mark.parametrize("ds", [2, 3])
+def test_ptm_frame_downsampling_bit_exact(oracle_mod, means_en, ds):
+    """ds > 1 (src/ptm_mgau.c:241: codebooks are re-scanned only every ds-th frame, the frames in
+    between re-score the carried codewords) makes every frame depend on its predecessor: the batch
+    call takes the exact chain kernel.  Ragged batch, top-N order included."""
+    import soundswallower_amd as ssw
+    mdir = ssw.model_dir("en-us")
+    g = ssw.Model(mdir, config={"ds": ds})
+    o = oracle_mod.Model(mdir, config={"ds": ds})
+    lens = [37, 1, 64, 130]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    feats = np.concatenate([synth_features(means_en, n, 555 + i) for i, n in enumerate(lens)])
+    got = g.score_batch(feats, off)
+    gcw, _ = g.last_topn(len(feats))
+    ref, rcw, _ = _oracle_batch(o, feats, off)
+    assert np.array_equal(gcw.astype(np.int32), rcw)
+    assert np.array_equal(got, ref)
+
+
+def test_ptm_forced_exact_path_bit_exact(orc_en, means_en, monkeypatch):
+    """SSW_PTM_EXACT=1 scores whole batches with the exact chain kernel (no speculation): the same
+    scores and top-N state as the speculative path and the oracle."""
+    import soundswallower_amd as ssw
+    monkeypatch.setenv("SSW_PTM_EXACT", "1")
+    g = ssw.Model(ssw.model_dir("en-us"))
+    monkeypatch.delenv("SSW_PTM_EXACT")
+    lens = [200, 56]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    feats = np.concatenate([synth_features(means_en, n, 31 + i) for i, n in enumerate(lens)])
+    got = g.score_batch(feats, off)
+    flagged, pairs = g.last_stats()
+    assert flagged == pairs == len(feats) * 126      # every pair took the exact route
+    ref, rcw, _ = _oracle_batch(orc_en, feats, off)
+    gcw, _ = g.last_topn(len(feats))
+    assert np.array_equal(gcw.astype(np.int32), rcw)
+    assert np.array_equal(got, ref)
