@@ -161,3 +161,42 @@ def test_synthetic_feature_generator_is_pinned(means_en):
     assert f.shape == (4, 39) and f.dtype == np.float32
     cb, cw = int(np.floor(ref[0] * 42)), int(np.floor(ref[1] * 128))
     assert abs(float(f[0, 0]) - float(means_en[cb, 0, cw, 0])) <= 0.25
+
+
+def write_clustered_sendump(path, codes, codebook, n_feat, n_density, n_sen):
+    """A 4-bit clustered sendump (src/ptm_mgau.c:456-609): title, header, key strings, a zero
+    length, the 16-entry cluster codebook, then [feat][density][ceil(n_sen / 2)] packed bytes."""
+    def s(txt):
+        b = txt.encode() + b"\0"
+        return struct.pack("<i", len(b)) + b
+    blob = s("s3 senone dump") + s("synthetic, 4-bit clusters")
+    for kv in (f"feature_count {n_feat}", f"mixture_count {n_density}", f"model_count {n_sen}",
+               "cluster_count 15", "cluster_bits 4"):
+        blob += s(kv)
+    blob += struct.pack("<i", 0) + bytes(codebook)
+    blob += np.ascontiguousarray(codes, np.uint8).tobytes()
+    with open(path, "wb") as fh:
+        fh.write(blob)
+
+
+def synth_clustered_sendump(orc, path, seed=3):
+    rng = np.random.default_rng(seed)
+    codebook = np.sort(rng.choice(np.arange(1, 160), 16, replace=False)).astype(np.uint8)
+    step = (orc.n_sen + 1) // 2
+    codes = rng.integers(0, 256, size=(orc.n_feat, orc.n_density, step), dtype=np.uint8)
+    write_clustered_sendump(path, codes, codebook, orc.n_feat, orc.n_density, orc.n_sen)
+    # the reference picks the nibble by the packed byte's own low bit (ptm_mgau.c:375-378)
+    packed = np.repeat(codes, 2, axis=2)[:, :, :orc.n_sen]
+    code = np.where(packed & 1, packed >> 4, packed & 0x0F)
+    return codebook[code]
+
+
+def test_clustered_sendump_is_expanded_with_the_reference_rule(orc_en, tmp_path):
+    src = os.path.join(MODEL_ROOT, "en-us")
+    sd = str(tmp_path / "sendump4")
+    expect = synth_clustered_sendump(orc_en, sd)
+    m = ssw.Model(mdef=os.path.join(src, "mdef"), means=os.path.join(src, "means"),
+                  variances=os.path.join(src, "variances"), sendump=sd,
+                  tmat=os.path.join(src, "transition_matrices"), config={"device": -2})
+    got = m.table("ptm_mixw").reshape(expect.shape)
+    assert np.array_equal(got, expect)

@@ -160,3 +160,21 @@ def test_ptm_forced_exact_path_bit_exact(orc_en, means_en, monkeypatch):
     gcw, _ = g.last_topn(len(feats))
     assert np.array_equal(gcw.astype(np.int32), rcw)
     assert np.array_equal(got, ref)
+
+
+def test_ptm_clustered_4bit_sendump_bit_exact(oracle_mod, orc_en, means_en, tmp_path):
+    """A 4-bit clustered sendump: the product expands it once at load, the oracle decodes it per
+    lookup the way the reference does (nibble chosen by the packed byte's own low bit,
+    src/ptm_mgau.c:375-378); the scores must agree."""
+    import os
+    import soundswallower_amd as ssw
+    from tests.test_cabi_host import synth_clustered_sendump
+    src = ssw.model_dir("en-us")
+    sd = str(tmp_path / "sendump4")
+    synth_clustered_sendump(orc_en, sd, seed=9)
+    kw = dict(mdef=os.path.join(src, "mdef"), means=os.path.join(src, "means"), sendump=sd,
+              tmat=os.path.join(src, "transition_matrices"))
+    g = ssw.Model(variances=os.path.join(src, "variances"), **kw)
+    o = oracle_mod.Model(vars=os.path.join(src, "variances"), **kw)
+    feats = synth_features(means_en, 300, 2718)
+    assert np.array_equal(g.score_batch(feats), o.ptm_score_utt(feats))
