@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file lives in tests/)
 sys.path.insert(0, ROOT)
 import soundswallower_amd as ssw  # noqa: E402
 from oracle import oracle as O  # noqa: E402
