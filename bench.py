@@ -48,6 +48,45 @@ def algorithmic_bytes(n_sen, n_feat, topn, n_cb, n_density, veclen_total, batch)
             "senone_kernel": topn_b + mixw_b + out_b}
 
 
+def align_config3(ssw, model, means, torch, n_utts=256, n_frames=1000, n_phones=150, reps=3):
+    """BASELINE configs[2]: score and force-align 256 synthetic utterances x 1000 frames x 150
+    phones (the "align RTF" part of the metric); best of `reps` passes."""
+    from soundswallower_amd.synth import synth_alignment_task
+    sseq = model.table("sseq").reshape(-1, 3)
+    pssid, ptmat = model.table("phone_ssid"), model.table("phone_tmat")
+    feats = np.concatenate([ssw.synth_features(means, n_frames, 12345 + u) for u in range(n_utts)])
+    senid, tmat = [], []
+    for u in range(n_utts):
+        s_, t_, _ = synth_alignment_task(sseq, pssid, ptmat, model.n_ciphone, n_phones, 777 + u)
+        senid.append(s_)
+        tmat.append(t_)
+    senid, tmat = np.concatenate(senid), np.concatenate(tmat)
+    frame_off = (np.arange(n_utts + 1) * n_frames).astype(np.int32)
+    phone_off = (np.arange(n_utts + 1) * n_phones).astype(np.int32)
+    total = n_utts * n_frames
+    d_feats = torch.from_numpy(feats).cuda()
+    d_scr = torch.empty((total, model.n_sen), dtype=torch.int16, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.score_batch_device(d_feats, total, frame_off, d_scr, stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        st, status = model.align_batch(d_scr.data_ptr(), frame_off, phone_off, senid, tmat)
+        t2 = time.perf_counter()
+        if best is None or t2 - t0 < best[0]:
+            best = (t2 - t0, t1 - t0, t2 - t1)
+    tiles = all(st[phone_off[u] * 3:phone_off[u + 1] * 3, 1].sum() == n_frames
+                for u in range(n_utts) if status[u] == 0)
+    return {"workload": f"{n_utts} utterances x {n_frames} frames x {n_phones} phones, en-us: PTM "
+                        f"scoring + forced alignment (BASELINE configs[2])",
+            "score_ms": best[1] * 1e3, "align_ms": best[2] * 1e3,
+            "rtf": best[0] / (total / 100.0), "utt_frames_per_s": total / best[0],
+            "aligned": int((status == 0).sum()), "alignments_tile_their_utterances": bool(tiles)}
+
+
 def cpu_baseline(model_dir, feats, utt_off, target_s=12.0):
     """Time the CPU oracle (scalar C restatement of the reference path) on a bounded sample."""
     from oracle import oracle as O
@@ -73,6 +112,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--model", default="en-us")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-align", action="store_true",
+                    help="skip the config-3 alignment pass that fills the `align` object")
     ap.add_argument("--utts", type=int, default=N_UTTS,
                     help="utterances (x256 frames) per GPU per step; the default is BASELINE.json "
                          "configs[1], 4096 frames")
@@ -218,6 +259,8 @@ def main():
                       if valu_instr else None),
         "exact_pass_share": flagged / max(pairs, 1),
     }
+    if not args.no_align and world == 1 and args.model == "en-us":
+        out["align"] = align_config3(ssw, model, means, torch)
     if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(mdir, feats, utt_off)
     print(json.dumps(out), flush=True)
