@@ -207,6 +207,9 @@ class Model:
         _check(self._L.ssw_memcpy_h2d(p, _ptr(arr), arr.nbytes), "ssw_memcpy_h2d")
         return p
 
+    def device_malloc(self, nbytes: int) -> int:
+        return _check(self._L.ssw_device_malloc(int(nbytes)), "ssw_device_malloc")
+
     def device_free(self, p):
         self._L.ssw_device_free(p)
 

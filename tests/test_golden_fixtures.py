@@ -92,3 +92,46 @@ def test_loader_tables_match_committed_hashes(golden, name):
            "phone_ssid": crc(m.table("phone_ssid")), "logadd8": crc(m.table("logadd8"))}
     for k, v in got.items():
         assert v == g[k], k
+
+
+@pytest.mark.gpu
+def test_gpu_config3_full_size(golden, gpu_en, orc_en, means_en):
+    """BASELINE config 3 at its full size: 256 utterances x 1000 frames x 150 phones scored and
+    aligned in one batch each.  The first four utterances are the golden ones (oracle checksums
+    committed), every alignment must tile its utterance, and the batch result must not depend
+    on the batch: utterance 200 alone gives the same scores and states."""
+    n_utts, n_fr, n_ph = 256, 1000, 150
+    feats = np.concatenate([synth_features(means_en, n_fr, 12345 + u) for u in range(n_utts)])
+    frame_off = (np.arange(n_utts + 1) * n_fr).astype(np.int32)
+    phone_off = (np.arange(n_utts + 1) * n_ph).astype(np.int32)
+    senids, tmats = [], []
+    for u in range(n_utts):
+        s, t, _ = synth_alignment_task(orc_en.sseq, orc_en.phone_ssid, orc_en.phone_tmat,
+                                       orc_en.n_ciphone, n_ph, 777 + u)
+        senids.append(s)
+        tmats.append(t)
+    senid, tmat = np.concatenate(senids), np.concatenate(tmats)
+    d_feats = gpu_en.to_device(feats)
+    d_scr = gpu_en.device_malloc(n_utts * n_fr * gpu_en.n_sen * 2)
+    try:
+        gpu_en.score_batch_device(d_feats, n_utts * n_fr, frame_off, d_scr)
+        st, status = gpu_en.align_batch(d_scr, frame_off, phone_off, senid, tmat)
+    finally:
+        gpu_en.device_free(d_scr)
+        gpu_en.device_free(d_feats)
+    assert (status == 0).all()
+    for u in range(n_utts):
+        seg = st[phone_off[u] * 3:phone_off[u + 1] * 3]
+        assert seg[0, 0] == 0 and seg[:, 1].sum() == n_fr
+        assert np.array_equal(seg[1:, 0], np.cumsum(seg[:-1, 1]))
+    for u, g in enumerate(golden["config3_align"]):
+        assert crc(st[phone_off[u] * 3:phone_off[u + 1] * 3]) == g["states_crc"]
+    u = 200
+    scr1 = gpu_en.score_batch(feats[frame_off[u]:frame_off[u + 1]])
+    d = gpu_en.to_device(scr1)
+    try:
+        st1, status1 = gpu_en.align_batch(d, [0, n_fr], [0, n_ph], senids[u], tmats[u])
+    finally:
+        gpu_en.device_free(d)
+    assert status1[0] == 0
+    assert np.array_equal(st1, st[phone_off[u] * 3:phone_off[u + 1] * 3])
