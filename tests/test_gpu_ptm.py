@@ -178,3 +178,25 @@ def test_ptm_clustered_4bit_sendump_bit_exact(oracle_mod, orc_en, means_en, tmp_
     o = oracle_mod.Model(vars=os.path.join(src, "variances"), **kw)
     feats = synth_features(means_en, 300, 2718)
     assert np.array_equal(g.score_batch(feats), o.ptm_score_utt(feats))
+
+
+def test_ptm_edge_shapes(gpu_en, orc_en, means_en):
+    """Empty batch, empty utterances inside a batch, one-frame utterances, many tiny utterances:
+    the shapes the reference's tests call 'empty and ragged inputs'."""
+    assert gpu_en.score_batch(np.zeros((0, 39), np.float32)).shape == (0, orc_en.n_sen)
+    feats = synth_features(means_en, 40, 99)
+    # utterances of 0, 1, 0, 38, 1, 0 frames
+    off = np.array([0, 0, 1, 1, 39, 40, 40], np.int32)
+    got = gpu_en.score_batch(feats, off)
+    ref = np.concatenate([orc_en.ptm_score_utt(feats[off[u]:off[u + 1]])
+                          for u in range(len(off) - 1) if off[u + 1] > off[u]])
+    assert np.array_equal(got, ref)
+    # 600 one-frame utterances: every frame starts from the reset history
+    f1 = synth_features(means_en, 600, 100)
+    got1 = gpu_en.score_batch(f1, np.arange(601, dtype=np.int32))
+    ref1 = np.concatenate([orc_en.ptm_score_utt(f1[t:t + 1]) for t in range(600)])
+    assert np.array_equal(got1, ref1)
+    with pytest.raises(Exception):
+        gpu_en.score_batch(feats, np.array([0, 41], np.int32))      # offsets past the batch
+    with pytest.raises(Exception):
+        gpu_en.score_batch(feats, np.array([0, 30, 20, 40], np.int32))  # not ascending
