@@ -131,6 +131,86 @@ __global__ void __launch_bounds__(256) k(float *out, unsigned long long *cyc, fl
                 asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(L4) : "v"(L0), "v"(L2), "v"(L3));
                 asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(L1) : "v"(L4), "v"(L2), "v"(L3));
                 asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(L3) : "v"(L1), "v"(L2), "v"(L0));
+            } else if (MODE == 22) { // v_bfe_u32 in place
+                asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(iL0) : "v"(iL1));
+            } else if (MODE == 23) { // v_lshrrev_b32 in place
+                asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(iL0));
+                asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(iL0));
+                asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(iL0));
+                asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(iL0));
+            } else if (MODE == 24) { // v_lshlrev_b32 in place
+                asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(iL0));
+                asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(iL0));
+                asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(iL0));
+                asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(iL0));
+            } else if (MODE == 25) { // v_and_b32 in place
+                asm volatile("v_and_b32 %0, %0, %1" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_and_b32 %0, %0, %1" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_and_b32 %0, %0, %1" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_and_b32 %0, %0, %1" : "+v"(iL0) : "v"(iL1));
+            } else if (MODE == 26) { // v_or_b32 in place
+                asm volatile("v_or_b32 %0, %0, %1" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_or_b32 %0, %0, %1" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_or_b32 %0, %0, %1" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_or_b32 %0, %0, %1" : "+v"(iL0) : "v"(iL1));
+            } else if (MODE == 27) { // v_cndmask_b32 (vcc)
+                asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(iL0) : "v"(iL1));
+            } else if (MODE == 28) { // v_cmp_gt_i32 (to vcc)
+                asm volatile("v_cmp_gt_i32 vcc, %0, %1" :: "v"(iL0), "v"(iL1) : "vcc");
+                asm volatile("v_cmp_gt_i32 vcc, %0, %1" :: "v"(iL0), "v"(iL1) : "vcc");
+                asm volatile("v_cmp_gt_i32 vcc, %0, %1" :: "v"(iL0), "v"(iL1) : "vcc");
+                asm volatile("v_cmp_gt_i32 vcc, %0, %1" :: "v"(iL0), "v"(iL1) : "vcc");
+            } else if (MODE == 29) { // v_lshl_add_u32 in place
+                asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(iL0) : "v"(iL1));
+            } else if (MODE == 30) { // v_add3_u32 in place
+                asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(iL0) : "v"(iL1), "v"(iL2));
+                asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(iL0) : "v"(iL1), "v"(iL2));
+                asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(iL0) : "v"(iL1), "v"(iL2));
+                asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(iL0) : "v"(iL1), "v"(iL2));
+            } else if (MODE == 31) { // v_mul_u32_u24 in place
+                asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(iL0) : "v"(iL1));
+            } else if (MODE == 32) { // v_mad_u32_u24 in place
+                asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(iL0) : "v"(iL1), "v"(iL2));
+                asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(iL0) : "v"(iL1), "v"(iL2));
+                asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(iL0) : "v"(iL1), "v"(iL2));
+                asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(iL0) : "v"(iL1), "v"(iL2));
+            } else if (MODE == 33) { // v_perm_b32 in place
+                asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(iL0) : "v"(iL1), "v"(iL2));
+                asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(iL0) : "v"(iL1), "v"(iL2));
+                asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(iL0) : "v"(iL1), "v"(iL2));
+                asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(iL0) : "v"(iL1), "v"(iL2));
+            } else if (MODE == 34) { // v_max_i32 in place
+                asm volatile("v_max_i32 %0, %0, %1" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_max_i32 %0, %0, %1" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_max_i32 %0, %0, %1" : "+v"(iL0) : "v"(iL1));
+                asm volatile("v_max_i32 %0, %0, %1" : "+v"(iL0) : "v"(iL1));
+            } else if (MODE == 35) { // v_min3_i32 in place
+                asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(iL0) : "v"(iL1), "v"(iL2));
+                asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(iL0) : "v"(iL1), "v"(iL2));
+                asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(iL0) : "v"(iL1), "v"(iL2));
+                asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(iL0) : "v"(iL1), "v"(iL2));
+            } else if (MODE == 36) { // v_sub_u32_sdwa byte-byte
+                asm volatile("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2" : "=v"(iL0) : "v"(iL1), "v"(iL2));
+                asm volatile("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2" : "=v"(iL0) : "v"(iL1), "v"(iL2));
+                asm volatile("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2" : "=v"(iL0) : "v"(iL1), "v"(iL2));
+                asm volatile("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2" : "=v"(iL0) : "v"(iL1), "v"(iL2));
+            } else if (MODE == 37) { // v_mov_b32
+                asm volatile("v_mov_b32 %0, %1" : "=v"(iL0) : "v"(iL1));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(iL1) : "v"(iL0));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(iL0) : "v"(iL1));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(iL1) : "v"(iL0));
             } else if (MODE == 5) { // v_add_u32 (plain integer)
                 asm volatile("v_add_u32 %0, %0, %1" : "+v"(L0) : "v"(L1));
                 asm volatile("v_add_u32 %0, %0, %1" : "+v"(L0) : "v"(L1));
@@ -149,7 +229,7 @@ __global__ void __launch_bounds__(256) k(float *out, unsigned long long *cyc, fl
 template <int MODE>
 static void run(const char *name, float *out, unsigned long long *cyc)
 {
-    for (int w = 2; w <= 4; w *= 2) {
+    for (int w = 4; w <= 4; w *= 2) {
         int blocks = 256 * w; // 256 CUs x w blocks of 4 waves -> w waves per SIMD
         hipEvent_t e0, e1;
         hipEventCreate(&e0);
@@ -189,6 +269,22 @@ int main()
     run<9>("senone step (4 valu + ds_read_u8)", out, cyc);
     run<10>("v_and_or_b32", out, cyc);
     run<11>("v_min_f32 / v_max_f32", out, cyc);
+    run<22>("v_bfe_u32 in place", out, cyc);
+    run<23>("v_lshrrev_b32 in place", out, cyc);
+    run<24>("v_lshlrev_b32 in place", out, cyc);
+    run<25>("v_and_b32 in place", out, cyc);
+    run<26>("v_or_b32 in place", out, cyc);
+    run<27>("v_cndmask_b32 (vcc)", out, cyc);
+    run<28>("v_cmp_gt_i32 (to vcc)", out, cyc);
+    run<29>("v_lshl_add_u32 in place", out, cyc);
+    run<30>("v_add3_u32 in place", out, cyc);
+    run<31>("v_mul_u32_u24 in place", out, cyc);
+    run<32>("v_mad_u32_u24 in place", out, cyc);
+    run<33>("v_perm_b32 in place", out, cyc);
+    run<34>("v_max_i32 in place", out, cyc);
+    run<35>("v_min3_i32 in place", out, cyc);
+    run<36>("v_sub_u32_sdwa byte-byte", out, cyc);
+    run<37>("v_mov_b32", out, cyc);
     run<12>("v_add_u32 rotating dst", out, cyc);
     run<13>("v_sub_u32 in place", out, cyc);
     run<14>("v_min_i32 in place", out, cyc);
