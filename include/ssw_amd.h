@@ -72,10 +72,16 @@ int ssw_model_info(const ssw_model_t *m, ssw_model_info_t *out);
  * [cb][feat][density][veclen]; DET float32 [cb][feat][density]; PTM_MIXW uint8
  * [feat][density][n_sen]; MS_PDF uint8 [sen][feat][density]; TP uint8 [tmat][n][n+1];
  * SSEQ uint16 [n_sseq][n_emit]; SEN2CB int16 [n_sen]; LOGADD8 uint8[256];
- * PHONE_SSID / PHONE_TMAT int32 [n_phone]. */
+ * PHONE_SSID / PHONE_TMAT int32 [n_phone].  The last four are the device-layout Gaussian
+ * tables (no reference counterpart; exposed so the scan's error bound can be replayed on
+ * the CPU): REC float32 [cb*feat][density][32] = mean[0..15) | det[15] | scale[16..31);
+ * SCAN_REC the same shape holding the quadratic form a[0..15) | c[15] | b[16..31);
+ * SCAN_D0 float32 [cb*feat][32], element 0 = the codebook's reference det;
+ * SCAN_EXACT uint32 [cb*feat][132] = count, then the densities scored in the exact form. */
 enum ssw_table {
     SSW_TAB_MEAN = 0, SSW_TAB_VAR, SSW_TAB_DET, SSW_TAB_PTM_MIXW, SSW_TAB_MS_PDF, SSW_TAB_TP,
-    SSW_TAB_SSEQ, SSW_TAB_SEN2CB, SSW_TAB_LOGADD8, SSW_TAB_PHONE_SSID, SSW_TAB_PHONE_TMAT
+    SSW_TAB_SSEQ, SSW_TAB_SEN2CB, SSW_TAB_LOGADD8, SSW_TAB_PHONE_SSID, SSW_TAB_PHONE_TMAT,
+    SSW_TAB_REC, SSW_TAB_SCAN_REC, SSW_TAB_SCAN_D0, SSW_TAB_SCAN_EXACT
 };
 const void *ssw_model_table(const ssw_model_t *m, int which, size_t *nbytes);
 

@@ -93,6 +93,8 @@ def lib() -> C.CDLL:
     L.orc_fe_mfcc.argtypes = [vp, C.c_size_t, C.c_int, f64, f64, C.c_int, C.c_int, C.c_int, vp, C.c_int]
     L.orc_feat_1s_c_d_dd.argtypes = [vp, C.c_int, vp]
     L.orc_hmm_vit_eval.restype = i32
+    L.orc_scan_replay.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+    L.orc_scan_replay.restype = None
     L.orc_hmm_vit_eval.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp]
     _LIB = L
     return L
@@ -356,3 +358,18 @@ def phone_id_nearest(model: "Model", b: int, l: int, r: int, pos: int) -> int:
     L = lib()
     _bind_mdef(L)
     return L.orc_mdef_phone_id_nearest(model._m, int(b), int(l), int(r), int(pos))
+
+
+def scan_replay(rec, recq, x, veclen):
+    """rec / recq: float32 [n_density][32] of one codebook-stream; x: float32 [n][>= veclen].
+    Returns (ref, key), float32 [n][n_density]: the reference's density value and the GPU
+    scan's quadratic-form key, each with the exact fp32 operation order."""
+    rec = np.ascontiguousarray(rec, np.float32).reshape(-1, 32)
+    recq = np.ascontiguousarray(recq, np.float32).reshape(-1, 32)
+    x = np.ascontiguousarray(x, np.float32)
+    n, nd = x.shape[0], rec.shape[0]
+    ref = np.empty((n, nd), np.float32)
+    key = np.empty((n, nd), np.float32)
+    lib().orc_scan_replay(_ptr(rec), _ptr(recq), nd, veclen, _ptr(x), n, x.shape[1], _ptr(ref),
+                          _ptr(key))
+    return ref, key

@@ -1067,6 +1067,33 @@ density(const float *x, const float *mean, const float *var, float det, int len)
     return d;
 }
 
+/* Replay of the GPU scan's arithmetic, for tests/test_scan_bound.py (no reference
+ * counterpart: the reference only has the exact form above).  For every frame x[i] and every
+ * density of one codebook-stream: ref = the reference's fp32 density value from the exact
+ * record (mean | det at [15] | scale at [16..]), key = the quadratic form of the scan record
+ * (a | c at [15] | b at [16..]) accumulated the way the kernel does it: c, then for each
+ * dimension fma(a, x, .) and fma(b, fl(x*x), .), each rounded once (fmaf). */
+void
+orc_scan_replay(const float *rec, const float *recq, int n_density, int veclen,
+                const float *x, int n, int x_stride, float *ref_out, float *key_out)
+{
+    int i, d, j;
+    for (i = 0; i < n; ++i) {
+        const float *xi = x + (size_t)i * x_stride;
+        for (d = 0; d < n_density; ++d) {
+            const float *r = rec + (size_t)d * 32, *q = recq + (size_t)d * 32;
+            float k = q[15];
+            for (j = 0; j < veclen; ++j) {
+                float xx = xi[j] * xi[j];
+                k = fmaf(q[j], xi[j], k);
+                k = fmaf(q[16 + j], xx, k);
+            }
+            ref_out[(size_t)i * n_density + d] = density(xi, r, r + 16, r[15], veclen);
+            key_out[(size_t)i * n_density + d] = k;
+        }
+    }
+}
+
 /* (int32)d with the reference's clamp, src/ptm_mgau.c:128-131, 218-221 */
 static int32_t
 dens2int(float d)

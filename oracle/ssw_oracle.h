@@ -136,6 +136,10 @@ int orc_state_align(const orc_model_t *m, const uint8_t *tp_override, const int1
                     const int32_t *ef, orc_align_entry_t *state_io,
                     orc_align_entry_t *phone_out, int32_t *best_score_trace);
 
+/* test helper: the reference's density values next to the GPU scan's quadratic-form keys */
+void orc_scan_replay(const float *rec, const float *recq, int n_density, int veclen,
+                     const float *x, int n, int x_stride, float *ref_out, float *key_out);
+
 /* One hmm_vit_eval step on a bare HMM (src/hmm.c:741-759) for unit tests.
  * score/history have n_emit entries; out[0]=out_score, out[1]=out_history. Returns bestscore. */
 int32_t orc_hmm_vit_eval(int n_emit, const uint8_t *tp /* [n_emit][n_emit+1] */,

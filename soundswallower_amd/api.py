@@ -24,6 +24,8 @@ _TABLES = {
     "ptm_mixw": (3, np.uint8), "ms_pdf": (4, np.uint8), "tp": (5, np.uint8),
     "sseq": (6, np.uint16), "sen2cb": (7, np.int16), "logadd8": (8, np.uint8),
     "phone_ssid": (9, np.int32), "phone_tmat": (10, np.int32),
+    "rec": (11, np.float32), "scan_rec": (12, np.float32), "scan_d0": (13, np.float32),
+    "scan_exact": (14, np.uint32),
 }
 
 

@@ -21,6 +21,8 @@ extern "C" {
 #define SSW_REC_DET 15
 #define SSW_REC_VAR 16
 #define SSW_MAX_VECLEN 15
+/* per codebook-stream: [0] count, [1..] codewords the quadratic scan leaves to the exact form */
+#define SSW_EXLIST_STRIDE 132
 
 /* Host-side model: every table derived exactly as the reference derives it. */
 typedef struct ssw_host_model_s {
@@ -29,6 +31,14 @@ typedef struct ssw_host_model_s {
     int32_t n_cb, n_feat, n_density, veclen_total, n_floored;
     int32_t veclen[SSW_MAX_FEAT], featoff[SSW_MAX_FEAT];
     float *mean, *var, *det; /* file order / [cb][feat][density] */
+    /* device-layout Gaussian tables (ssw_host_build_records):
+     *   rec     [cb*feat][density][32]  exact records (mean, det, scale)
+     *   recq    [cb*feat][density][32]  quadratic-form scan records (a, c, b)
+     *   recd0   [cb*feat][32]           [0] = the codebook's reference det d0
+     *   exlist  [cb*feat][SSW_EXLIST_STRIDE] */
+    float *rec, *recq, *recd0;
+    uint32_t *exlist;
+    int32_t n_exact_form;
     /* mdef */
     int32_t n_ciphone, n_phone, n_emit_state, n_ci_sen, n_sen, n_tmat, n_sseq, sil;
     uint16_t *sseq;
@@ -56,6 +66,7 @@ ssw_host_model_t *ssw_host_model_load(const char *mdef, const char *means,
                                       const char *mixw, const char *tmat,
                                       const ssw_config_t *cfg);
 void ssw_host_model_free(ssw_host_model_t *h);
+int ssw_host_build_records(ssw_host_model_t *h);
 void ssw_set_error(const char *fmt, ...);
 
 #ifdef __cplusplus

@@ -702,6 +702,111 @@ bad:
 }
 
 /* ---------------------------------------------------------------------------------- */
+/* ---------------------------------------------------------------------------------- */
+/* device-layout Gaussian records and the quadratic-form scan records                   */
+/* ---------------------------------------------------------------------------------- */
+static int
+cmp_float(const void *a, const void *b)
+{
+    float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
+/* The speculative scan evaluates  det - sum var (x - mean)^2  as a quadratic form in x,
+ *   key = c + sum_j (a_j x_j + b_j x_j^2),  a = 2 var mean,  b = -var,
+ *   c = (det - d0) - R + bias,  R = sum var mean^2,  d0 = the codebook's median det,
+ * with 26 fused multiply-adds.  With u = 2^-24, S = sum var (x - mean)^2 and
+ * M = |det - d0| + R + sum |a x| + sum |b| x^2 <= |det - d0| + 6 R + 3 S
+ * (Cauchy-Schwarz), the form is within 27 u M of the real number and the reference's
+ * fp32 value within 13 u |det| + 17 u S of it (13 subtractions whose partial sums lie
+ * between det and the result; (1+u)^4 on every product); with
+ * S <= |det - d0| + |value - d0| that is u (125 |det - d0| + 162 R + 13 |det|) -- folded
+ * into c as `bias` with a few per cent of slack, so the key is an upper bound -- plus
+ * 98 u |value - d0|, which the kernel adds (104 u |key| + 0.001: |value| and |key| differ
+ * by at most the bias) to the one key it uses as a bound.  Densities whose bias would
+ * exceed 4 score units (floored variances far from the origin) get an inert scan record
+ * and go on the codebook's exact-form list: the kernel evaluates them the reference's
+ * way after the scan.  tests/test_scan_bound.py replays the kernel's arithmetic on the
+ * CPU against these tables. */
+int
+ssw_host_build_records(ssw_host_model_t *h)
+{
+    const int ncbf = h->n_cb * h->n_feat;
+    const size_t nrec = (size_t)ncbf * h->n_density;
+    const double u24 = 1.0 / 16777216.0;
+    const float *mp = h->mean, *vp = h->var;
+    float *dets;
+    int c, f, d, j, cbf;
+
+    if (h->n_density > SSW_EXLIST_STRIDE - 1) {
+        ssw_set_error("%d densities per codebook: at most %d are supported", h->n_density,
+                      SSW_EXLIST_STRIDE - 1);
+        return -1;
+    }
+    h->rec = (float *)calloc(nrec * SSW_REC_FLOATS, sizeof(float));
+    h->recq = (float *)calloc(nrec * SSW_REC_FLOATS, sizeof(float));
+    h->recd0 = (float *)calloc((size_t)ncbf * SSW_REC_FLOATS, sizeof(float));
+    h->exlist = (uint32_t *)calloc((size_t)ncbf * SSW_EXLIST_STRIDE, sizeof(uint32_t));
+    dets = (float *)malloc(sizeof(float) * (size_t)h->n_density);
+    if (!h->rec || !h->recq || !h->recd0 || !h->exlist || !dets) {
+        free(dets);
+        ssw_set_error("out of memory building the Gaussian records");
+        return -1;
+    }
+    for (c = 0; c < h->n_cb; ++c)
+        for (f = 0; f < h->n_feat; ++f)
+            for (d = 0; d < h->n_density; ++d) {
+                float *r = h->rec + (((size_t)c * h->n_feat + f) * h->n_density + d) * SSW_REC_FLOATS;
+                for (j = 0; j < h->veclen[f]; ++j) {
+                    r[j] = *mp++;
+                    r[SSW_REC_VAR + j] = *vp++;
+                }
+                r[SSW_REC_DET] = h->det[((size_t)c * h->n_feat + f) * h->n_density + d];
+            }
+    h->n_exact_form = 0;
+    for (cbf = 0; cbf < ncbf; ++cbf) {
+        uint32_t *xl = h->exlist + (size_t)cbf * SSW_EXLIST_STRIDE;
+        float d0;
+        for (d = 0; d < h->n_density; ++d)
+            dets[d] = h->rec[((size_t)cbf * h->n_density + d) * SSW_REC_FLOATS + SSW_REC_DET];
+        qsort(dets, (size_t)h->n_density, sizeof(float), cmp_float);
+        d0 = dets[h->n_density / 2];
+        h->recd0[(size_t)cbf * SSW_REC_FLOATS] = d0;
+        for (d = 0; d < h->n_density; ++d) {
+            const float *r = h->rec + ((size_t)cbf * h->n_density + d) * SSW_REC_FLOATS;
+            float *q = h->recq + ((size_t)cbf * h->n_density + d) * SSW_REC_FLOATS;
+            const double det = r[SSW_REC_DET], delta = det - (double)d0;
+            double R = 0.0, bias, cc;
+            int finite = isfinite(det);
+            float cf;
+            for (j = 0; j < SSW_MAX_VECLEN; ++j) {
+                double mean = r[j], var = r[SSW_REC_VAR + j];
+                R += fabs(var) * mean * mean;
+                finite = finite && isfinite(mean) && isfinite(var) && var >= 0.0;
+            }
+            bias = 1.05 * u24 * (126.0 * fabs(delta) + 164.0 * R + 14.0 * fabs(det));
+            if (!finite || !(bias <= 4.0)) {
+                xl[1 + xl[0]++] = (uint32_t)d;
+                q[SSW_REC_DET] = -3.0e38f; /* a = b = 0: the key stays out of the way */
+                ++h->n_exact_form;
+                continue;
+            }
+            for (j = 0; j < SSW_MAX_VECLEN; ++j) {
+                q[j] = (float)(2.0 * (double)r[SSW_REC_VAR + j] * (double)r[j]);
+                q[SSW_REC_VAR + j] = -r[SSW_REC_VAR + j];
+            }
+            cc = delta - R + bias;
+            cf = (float)cc;
+            if ((double)cf < cc)
+                cf = nextafterf(cf, INFINITY);
+            q[SSW_REC_DET] = cf;
+        }
+    }
+    free(dets);
+    return 0;
+}
+
+
 ssw_host_model_t *
 ssw_host_model_load(const char *mdef, const char *means, const char *variances,
                     const char *sendump, const char *mixw, const char *tmat,
@@ -738,6 +843,8 @@ ssw_host_model_load(const char *mdef, const char *means, const char *variances,
     if (mdef && load_mdef(h, mdef) < 0)
         goto bad;
     if (load_gaussians(h, &lb, means, variances) < 0)
+        goto bad;
+    if (ssw_host_build_records(h) < 0)
         goto bad;
     if (tmat && load_tmat(h, &lb, tmat) < 0)
         goto bad;
@@ -777,6 +884,10 @@ ssw_host_model_free(ssw_host_model_t *h)
     free(h->mean);
     free(h->var);
     free(h->det);
+    free(h->rec);
+    free(h->recq);
+    free(h->recd0);
+    free(h->exlist);
     free(h->sseq);
     free(h->sen2cb);
     free(h->phone_ssid);

@@ -1,0 +1,165 @@
+"""The proof obligation of the GPU's speculative top-N scan, replayed on the CPU.
+
+The frames kernel (soundswallower_amd/csrc/ssw_k1a_frames.inc) ranks the 128 densities of a
+codebook with a 26-FMA quadratic form instead of the reference's sub/mul/mul/sub chain
+(src/ptm_mgau.c:63-68), and accepts the speculative top four only when the fifth key, widened,
+is below the fourth exact score.  That is sound only if, for every density and every input,
+
+    widen(key) >= the reference's fp32 density value,
+
+with widen() the kernel's three fp32 statements.  The scan records are built on the host
+(ssw_model.c:ssw_host_build_records), so the inequality can be checked here without a GPU:
+oracle.scan_replay evaluates both sides with the exact operation order (fmaf for the kernel's
+v_fma_f32), over the shipped models and over input families chosen to stress the bound."""
+import os
+
+import numpy as np
+import pytest
+
+import soundswallower_amd as ssw
+from tests.conftest import MODEL_ROOT
+
+def widen(key, d0):
+    """The three statements after the scan (ssw_k1a_frames.inc, 'upper bound on the true
+    value of every density outside the four'), in float32 like the kernel."""
+    key = key.astype(np.float32)
+    ub = key + np.abs(key) * np.float32(104.0 * 2.0 ** -24) + np.float32(1.0e-3)
+    ub = ub + np.float32(d0)
+    ub = ub + np.abs(ub) * np.float32(2.0 ** -22)
+    return ub
+
+
+def bucket_up(key):
+    """The 5th key as the kernel sees it: low 7 mantissa bits were borrowed for the codeword
+    and are pushed towards +inf."""
+    b = key.astype(np.float32).view(np.uint32)
+    neg = (b & np.uint32(0x80000000)) != 0
+    return np.where(neg, b & np.uint32(0xFFFFFF80), b | np.uint32(127)).astype(np.uint32).view(np.float32)
+
+
+def input_families(mean4, f, n, rng):
+    """x for stream f, [n][veclen]: near the means (what speech looks like to the model), noise
+    at several scales, points far out along single axes, midpoints between densities, and
+    near-cancellation points x = mean (1 + eps) of the densities with the largest var mean^2."""
+    n_cb, n_feat, n_den, vl = mean4.shape
+    mu = mean4[:, f].reshape(-1, vl).astype(np.float32)
+    out = []
+    pick = mu[rng.integers(0, len(mu), n)]
+    out.append(pick + ((rng.random((n, vl)) - 0.5) * 0.5).astype(np.float32))
+    for sigma in (0.05, 1.0, 4.0, 25.0):
+        out.append((rng.standard_normal((n, vl)) * sigma).astype(np.float32))
+    far = pick.copy()
+    far[np.arange(n), rng.integers(0, vl, n)] += (rng.choice([-1, 1], n) * rng.uniform(10, 300, n)).astype(np.float32)
+    out.append(far)
+    out.append(((pick + mu[rng.integers(0, len(mu), n)]) * np.float32(0.5)).astype(np.float32))
+    out.append((pick * (1.0 + rng.uniform(-1e-3, 1e-3, (n, vl)))).astype(np.float32))
+    out.append(np.zeros((4, vl), np.float32))
+    return np.concatenate(out).astype(np.float32)
+
+
+def m_exact_expected(name):
+    """Densities left to the exact form in the shipped models."""
+    return {"en-us": 114, "fr-fr": 115}[name]
+
+
+@pytest.mark.parametrize("name", ["en-us", "fr-fr"])
+def test_scan_key_bounds_the_reference_value(oracle_mod, name):
+    m = ssw.Model(os.path.join(MODEL_ROOT, name), config={"device": -2})
+    o = oracle_mod.Model(os.path.join(MODEL_ROOT, name))
+    n_cbf, nd = m.n_cb * m.n_feat, m.n_density
+    rec = m.table("rec").reshape(n_cbf, nd, 32)
+    recq = m.table("scan_rec").reshape(n_cbf, nd, 32)
+    d0 = m.table("scan_d0").reshape(n_cbf, 32)[:, 0]
+    exl = m.table("scan_exact").reshape(n_cbf, -1)
+    mean4 = o.mean4()
+    vl = mean4.shape[3]
+    rng = np.random.default_rng(20240611)
+    n_pairs = 0
+    n_exact = 0
+    worst_margin = np.inf      # min of widen(key) - ref, in score units
+    worst_use = 0.0            # max of (ref - d0 - key) / (104u|key| + 1e-3): share of the widening used
+    # every codebook-stream of the model; several hundred inputs each (seconds on the CPU)
+    for cbf in range(n_cbf):
+        f = cbf % m.n_feat
+        x = input_families(mean4, f, 96, rng)
+        ref, key = oracle_mod.scan_replay(rec[cbf], recq[cbf], x, vl)
+        on_list = np.zeros(nd, bool)
+        on_list[exl[cbf, 1:1 + exl[cbf, 0]]] = True
+        n_exact += int(on_list.sum())
+        # exact-form densities: inert record, the key never competes
+        assert np.all(key[:, on_list] == np.float32(-3.0e38))
+        k, r = key[:, ~on_list], ref[:, ~on_list]
+        assert np.isfinite(k).all() and np.isfinite(r).all()
+        ub = widen(k, d0[cbf])
+        assert np.all(ub >= r), (name, cbf, float((ub - r).min()))
+        # what the kernel really uses is the bucketed 5th key, which is no smaller
+        assert np.all(bucket_up(k) >= k)
+        worst_margin = min(worst_margin, float((ub.astype(np.float64) - r).min()))
+        over = r.astype(np.float64) - float(d0[cbf]) - k.astype(np.float64)
+        room = 104.0 * 2.0 ** -24 * np.abs(k.astype(np.float64)) + 1.0e-3
+        worst_use = max(worst_use, float((over / room).max()))
+        n_pairs += k.size
+    assert n_exact == m_exact_expected(name)
+    assert n_pairs > 8_000_000
+    # the analysis leaves slack: the key exceeded by at most this share of the widening
+    assert worst_use < 1.0
+    print(f"{name}: {n_pairs} (input, density) pairs, min margin {worst_margin:.4g}, "
+          f"largest share of the widening used {worst_use:.3f}")
+
+
+def test_widening_is_monotone():
+    """The kernel widens only the 5th key and relies on widen() being non-decreasing, so that
+    it bounds every smaller key's density as well."""
+    rng = np.random.default_rng(5)
+    mags = np.exp(rng.uniform(np.log(1e-6), np.log(3e9), 400_000)).astype(np.float32)
+    v = np.sort(np.concatenate([mags, -mags, np.float32([0.0, -0.0])]))
+    # neighbours in float order stress the rounding of each statement
+    v = np.sort(np.concatenate([v, np.nextafter(v, np.float32(np.inf))]))
+    for d0 in (0.0, -73000.0, 41000.0, -1.0e7):
+        w = widen(v, d0)
+        assert np.all(np.diff(w) >= 0)
+
+
+def write_hostile_gaussians(tmp_path, n_cb=2, n_feat=3, nd=128, vl=13, seed=11):
+    """means / variances files (s3 gauden parameter layout, src/ms_gauden.c:105-216) with
+    means up to a few hundred and variances from below the floor to 10."""
+    from tests.test_cabi_host import _write_s3
+    import struct
+    rng = np.random.default_rng(seed)
+    scale = rng.choice([1.0, 30.0, 300.0], (n_cb, n_feat, nd, 1))
+    mean = (rng.standard_normal((n_cb, n_feat, nd, vl)) * scale).astype("<f4")
+    var = np.exp(rng.uniform(np.log(1e-5), np.log(10.0), (n_cb, n_feat, nd, vl))).astype("<f4")
+    paths = {}
+    for nm, arr in (("means", mean), ("variances", var)):
+        payload = struct.pack("<3i", n_cb, n_feat, nd) + struct.pack(f"<{n_feat}i", *([vl] * n_feat))
+        payload += struct.pack("<i", arr.size) + arr.tobytes()
+        paths[nm] = str(tmp_path / nm)
+        _write_s3(paths[nm], payload)
+    return paths
+
+
+def test_scan_bound_on_a_hostile_model(oracle_mod, tmp_path):
+    """Records with large means and tight variances (big var mean^2, where the quadratic form
+    cancels badly): those the bias cannot cover must land on the exact-form list, the rest must
+    still satisfy the bound."""
+    paths = write_hostile_gaussians(tmp_path)
+    m = ssw.Model(config={"device": -2}, **paths)
+    n_cbf, nd = m.n_cb * m.n_feat, m.n_density
+    rec = m.table("rec").reshape(n_cbf, nd, 32)
+    recq = m.table("scan_rec").reshape(n_cbf, nd, 32)
+    d0 = m.table("scan_d0").reshape(n_cbf, 32)[:, 0]
+    exl = m.table("scan_exact").reshape(n_cbf, -1)
+    assert exl[:, 0].sum() > 0
+    rng = np.random.default_rng(9)
+    vl = 13
+    for cbf in range(n_cbf):
+        mu = rec[cbf, :, :vl]
+        pick = mu[rng.integers(0, nd, 256)]
+        x = np.concatenate([pick + rng.standard_normal((256, vl)).astype(np.float32) * 0.3,
+                            pick * np.float32(1.0001),
+                            rng.standard_normal((256, vl)).astype(np.float32) * 50]).astype(np.float32)
+        ref, key = oracle_mod.scan_replay(rec[cbf], recq[cbf], x, vl)
+        on_list = np.zeros(nd, bool)
+        on_list[exl[cbf, 1:1 + exl[cbf, 0]]] = True
+        k, r = key[:, ~on_list], ref[:, ~on_list]
+        assert np.all(widen(k, d0[cbf]) >= r)
