@@ -1835,6 +1835,38 @@ orc_hmm_vit_eval(int n_emit, const uint8_t *tp, const int16_t *senscr, const uin
     return best;
 }
 
+/* hmm_vit_eval over a set of HMMs held in flat arrays (the first-pass restatement in
+ * oracle/fsg_oracle.py keeps its lextree nodes that way): nodes idx[0..n) are stepped in place
+ * with the model's transition matrices; best[] gets hmm_bestscore.  src/hmm.c:741-759. */
+void
+orc_hmm_vit_eval_many(const orc_model_t *m, const int16_t *senscr, int n, const int32_t *idx,
+                      const uint16_t *senid, const int16_t *tmat, int32_t *score,
+                      int32_t *hist, int32_t *out_score, int32_t *out_hist, int32_t *best)
+{
+    int k, i;
+    const int n_emit = m->n_emit_state;
+    for (k = 0; k < n; ++k) {
+        const int32_t p = idx[k];
+        ohmm_t h;
+        memset(&h, 0, sizeof(h));
+        h.n_emit = n_emit;
+        for (i = 0; i < n_emit; ++i) {
+            h.score[i] = score[(size_t)p * n_emit + i];
+            h.history[i] = hist[(size_t)p * n_emit + i];
+            h.senid[i] = senid[(size_t)p * n_emit + i];
+        }
+        h.out_score = out_score[p];
+        h.out_history = out_hist[p];
+        best[p] = ohmm_vit_eval(&h, m->tp + (size_t)tmat[p] * n_emit * (n_emit + 1), senscr);
+        for (i = 0; i < n_emit; ++i) {
+            score[(size_t)p * n_emit + i] = h.score[i];
+            hist[(size_t)p * n_emit + i] = h.history[i];
+        }
+        out_score[p] = h.out_score;
+        out_hist[p] = h.out_history;
+    }
+}
+
 /* ================================================================================== */
 /* state alignment: src/state_align_search.c + alignment_propagate                     */
 /* ================================================================================== */

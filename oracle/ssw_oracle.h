@@ -136,6 +136,11 @@ int orc_state_align(const orc_model_t *m, const uint8_t *tp_override, const int1
                     const int32_t *ef, orc_align_entry_t *state_io,
                     orc_align_entry_t *phone_out, int32_t *best_score_trace);
 
+/* hmm_vit_eval (src/hmm.c:741-759) over HMMs held in flat arrays; see oracle/fsg_oracle.py */
+void orc_hmm_vit_eval_many(const orc_model_t *m, const int16_t *senscr, int n, const int32_t *idx,
+                           const uint16_t *senid, const int16_t *tmat, int32_t *score,
+                           int32_t *hist, int32_t *out_score, int32_t *out_hist, int32_t *best);
+
 /* test helper: the reference's density values next to the GPU scan's quadratic-form keys */
 void orc_scan_replay(const float *rec, const float *recq, int n_density, int veclen,
                      const float *x, int n, int x_stride, float *ref_out, float *key_out);
