@@ -221,6 +221,71 @@ int32_t ssw_alignment_populate(const ssw_model_t *m, const ssw_dict_t *d, int32_
                                int32_t *tmatid, int32_t *cipid, int32_t *parent,
                                int32_t *ph_start, int32_t *ph_duration);
 
+/* Dictionary word ids (dict_wordid / dict_wordstr); alternates are words of their own,
+ * "forward(2)".  ssw_dict_word returns NULL and ssw_dict_word_id -1 when unknown. */
+const char *ssw_dict_word(const ssw_dict_t *d, int32_t wid);
+int32_t ssw_dict_word_id(const ssw_dict_t *d, const char *word);
+
+/* ------------------------------------------------------------------------------------ */
+/* First pass of forced alignment: which fillers and alternate          */
+/* pronunciations the text is spoken with, and every word's frames -- the word windows the  */
+/* second pass (ssw_align_batch) is constrained to.  Replaces, for the linear grammar        */
+/* decoder_set_align_text builds (src/decoder.c:686-735):                                    */
+/*   fsg_search_init: silence / filler loops, alternates     src/fsg_search.c:84-170, 172-253 */
+/*   fsg_lextree_init: per-state phone trees                 src/fsg_lextree.c:85-276, 356-660 */
+/*   fsg_search_start / _step / _finish: beam Viterbi        src/fsg_search.c:665-852          */
+/*   fsg_history_entry_add: word exits                       src/fsg_history.c:129-205         */
+/*   fsg_search_find_exit / _seg_iter: backtrace             src/fsg_search.c:854-925,1085-1143 */
+/* The graphs are built on the host, the search runs on the GPU, one workgroup per          */
+/* utterance, over senone scores already in HBM (ssw_score_batch).                          */
+/* ------------------------------------------------------------------------------------ */
+typedef struct ssw_first_pass_config_s {
+    double beam, pbeam, wbeam; /* 1e-48, 1e-48, 7e-29 (config_defs.h) */
+    double wip, pip;           /* 0.65, 1.0 */
+    float lw;                  /* 6.5 */
+    float silprob, fillprob;   /* 0.005, 1e-8 */
+    int32_t use_filler;        /* fsgusefiller, 1 */
+    int32_t use_altpron;       /* fsgusealtpron, 1 */
+} ssw_first_pass_config_t;
+void ssw_first_pass_config_defaults(ssw_first_pass_config_t *cfg);
+
+typedef struct ssw_word_seg_s {
+    int32_t wid;      /* dictionary word id (ssw_dict_word): text word, alternate or filler */
+    int32_t start;    /* first frame */
+    int32_t duration; /* frames */
+    int32_t score;    /* path score at the word's exit (fsg_hist_entry_score) */
+} ssw_word_seg_t;
+
+/* d_senscr: int16 [n_frames][n_sen] device scores of the whole batch (utterance u owns
+ * frames utt_off[u] .. utt_off[u+1]); words: the texts, utterance u = words[word_off[u] ..
+ * word_off[u+1]).  seg: [n_utts][max_seg]; n_seg[u] = segments written, or -1 when the
+ * grammar's final state is not reached in the last frame that has word exits ("Final result
+ * does not match the grammar", src/fsg_search.c:913-916) or max_seg is too small.
+ * cfg NULL = defaults.  Returns 0, or -1 (unknown word, graph too large, no device).
+ * Synchronous on `stream`. */
+int ssw_first_pass_batch(ssw_model_t *m, const ssw_dict_t *d, const ssw_first_pass_config_t *cfg,
+                         const int16_t *d_senscr, int32_t n_frames, const int32_t *utt_off,
+                         int32_t n_utts, const int32_t *word_off, const char *const *words,
+                         int32_t max_seg, int32_t *n_seg, ssw_word_seg_t *seg, void *stream);
+
+/* The graph ssw_first_pass_batch searches for one text, node by node (host only, works without
+ * a device): the phone-tree HMMs of fsg_lextree_init with their entry penalty, predecessor,
+ * FSG state and context sets.  flags: 1 word-initial, 2 word-final, 4 exit valid for every
+ * right context.  beams[3] receives beam, pbeam, wbeam in score units.  Returns the node
+ * count (which may exceed max_nodes: only max_nodes are written) or -1. */
+typedef struct ssw_fp_node_s {
+    uint16_t senid[3];
+    int16_t tmat;
+    int32_t pen, parent;
+    uint32_t flags;
+    int32_t ci_ext, state, to_state, wid;
+    uint64_t ctxt;
+} ssw_fp_node_t;
+int32_t ssw_first_pass_graph(const ssw_model_t *m, const ssw_dict_t *d,
+                             const ssw_first_pass_config_t *cfg, int32_t n_words,
+                             const char *const *words, int32_t max_nodes, ssw_fp_node_t *nodes,
+                             int32_t *beams);
+
 /* decoder_result_json(d, utt_start, align_level >= 1) (src/decoder.c:1339-1593): the one-line
  * JSON the reference prints for an alignment, {"b","d","p","t","w":[...]} with b/d in seconds
  * (frames / frate) and p = logmath_exp(score).  hyp / hyp_logprob are the first pass's text

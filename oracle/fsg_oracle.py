@@ -34,36 +34,60 @@ POS_INTERNAL, POS_BEGIN, POS_END, POS_SINGLE = 0, 1, 2, 3
 
 
 class Lexicon:
-    """dict.txt + noisedict.txt (src/dict.c): pronunciations, alternates `word(2)`, fillers."""
+    """dict_init_s3file / dict_add_word (src/dict.c:72-134, 240-345): main dictionary, then the
+    filler dictionary, then <s>, </s>, <sil> when missing; `word(2)` is linked into its base
+    word's alternate list (newest first) and refused when the base is missing."""
 
     def __init__(self, model, dict_path, filler_path):
         self.pron = {}
-        self.alts = {}
-        self.fillers = []
-        self._read(model, dict_path, False)
-        self._read(model, filler_path, True)
+        self.order = []
+        self.alt = {}          # dict_nextalt
+        self._read(model, dict_path)
+        self.filler_start = len(self.order)
+        self._read(model, filler_path)
+        for w in ("<s>", "</s>", "<sil>"):
+            self._add(w, [model.sil])
+        self.fillers = set(self.order[self.filler_start:])
 
-    def _read(self, model, path, filler):
+    def _add(self, w, ci):
+        if w in self.pron:
+            return
+        m = re.match(r"^(.+)\((.*)\)$", w) if w.endswith(")") else None
+        if m:
+            # dict_word2basestr cuts at the LAST '(' that is not the first character
+            i = w.rfind("(", 1, len(w) - 1)
+            base = w[:i] if i > 0 else None
+            if base is not None:
+                if base not in self.pron:
+                    return
+                self.alt[w] = self.alt.get(base)
+                self.alt[base] = w
+        self.pron[w] = ci
+        self.order.append(w)
+
+    def _read(self, model, path):
         with open(path, encoding="utf-8") as fh:
             for line in fh:
                 parts = line.split()
-                if not parts or parts[0].startswith("##") or parts[0].startswith(";;"):
-                    continue
-                w = parts[0]
-                if w in self.pron:
+                if not parts or line.startswith("##") or line.startswith(";;"):
                     continue
                 ci = [O.ciphone_id(model, p) for p in parts[1:]]
-                if min(ci, default=-1) < 0:
+                if not ci or min(ci) < 0:
                     continue
-                self.pron[w] = ci
-                if filler:
-                    self.fillers.append(w)
-                m = re.match(r"^(.+)\((\d+)\)$", w)
-                if m and m.group(1) in self.pron:
-                    self.alts.setdefault(m.group(1), []).append(w)
+                self._add(parts[0], ci)
+
+    def alt_chain(self, w):
+        """the word, then dict_nextalt until it ends (fsg_search_add_altpron)."""
+        out = [w]
+        while self.alt.get(out[-1]) is not None:
+            out.append(self.alt[out[-1]])
+        return out
 
     def is_filler(self, w):
-        return w in self.fillers
+        """dict_filler_word: in the filler range, <s> and </s> excepted (by base word)."""
+        while w not in self.fillers and w.endswith(")") and w.rfind("(", 1) > 0 and w[:w.rfind("(", 1)] in self.pron:
+            w = w[:w.rfind("(", 1)]
+        return w in self.fillers and w not in ("<s>", "</s>")
 
 
 class Config:
@@ -111,18 +135,18 @@ def build_fsg(lex, words, lmath, cfg):
     for i, w in enumerate(words):
         if w not in lex.pron:
             raise KeyError(f"Unknown word {w}")
-        arcs[i].append(Link(i, i + 1, 0, w, False))
-        for a in lex.alts.get(w, ()):              # fsg_model_add_alt: same probability
+        for a in lex.alt_chain(w):                  # fsg_model_add_alt: same probability
             arcs[i].append(Link(i, i + 1, 0, a, False))
     logsil = int(np.float32(lmath.log(float(np.float32(cfg.silprob)))) * lw)
     logfil = int(np.float32(lmath.log(float(np.float32(cfg.fillprob)))) * lw)
+    # src/fsg_search.c:107-116: `wid < dict_filler_end` leaves the LAST filler word out
+    others = [f for f in lex.order[lex.filler_start:len(lex.order) - 1]
+              if f not in ("<s>", "</s>", "<sil>")]
     for s in range(n_state):
-        arcs[s].append(Link(s, s, logsil, "<sil>", True))
-        for f in lex.fillers:
-            if f in ("<s>", "</s>", "<sil>"):
-                continue
-            arcs[s].append(Link(s, s, logfil, f, True))
-            for a in lex.alts.get(f, ()):
+        for a in lex.alt_chain("<sil>"):
+            arcs[s].append(Link(s, s, logsil, a, True))
+        for f in others:
+            for a in lex.alt_chain(f):
                 arcs[s].append(Link(s, s, logfil, a, True))
     return arcs
 

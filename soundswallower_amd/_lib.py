@@ -114,6 +114,16 @@ def lib() -> C.CDLL:
     L.ssw_dict_size.argtypes = [vp]
     L.ssw_dict_pron.restype = i32
     L.ssw_dict_pron.argtypes = [vp, C.c_char_p, vp, i32]
+    L.ssw_dict_word.restype = C.c_char_p
+    L.ssw_dict_word.argtypes = [vp, i32]
+    L.ssw_dict_word_id.restype = i32
+    L.ssw_dict_word_id.argtypes = [vp, C.c_char_p]
+    L.ssw_first_pass_config_defaults.argtypes = [vp]
+    L.ssw_first_pass_config_defaults.restype = None
+    L.ssw_first_pass_graph.restype = i32
+    L.ssw_first_pass_graph.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp]
+    L.ssw_first_pass_batch.restype = C.c_int
+    L.ssw_first_pass_batch.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp]
     L.ssw_ciphone_name.restype = C.c_char_p
     L.ssw_ciphone_name.argtypes = [vp, i32]
     L.ssw_phone_id_nearest.restype = i32

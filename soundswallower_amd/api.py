@@ -33,6 +33,22 @@ class SswError(RuntimeError):
     pass
 
 
+class FirstPassConfig(C.Structure):
+    """ssw_first_pass_config_t"""
+    _fields_ = [("beam", C.c_double), ("pbeam", C.c_double), ("wbeam", C.c_double),
+                ("wip", C.c_double), ("pip", C.c_double), ("lw", C.c_float),
+                ("silprob", C.c_float), ("fillprob", C.c_float), ("use_filler", C.c_int32),
+                ("use_altpron", C.c_int32)]
+
+
+FP_NODE_DTYPE = np.dtype([("senid", np.uint16, 3), ("tmat", np.int16), ("pen", np.int32),
+                          ("parent", np.int32), ("flags", np.uint32), ("ci_ext", np.int32),
+                          ("state", np.int32), ("to_state", np.int32), ("wid", np.int32),
+                          ("ctxt", np.uint64)], align=True)
+WORD_SEG_DTYPE = np.dtype([("wid", np.int32), ("start", np.int32), ("duration", np.int32),
+                           ("score", np.int32)])
+
+
 def _ptr(a):
     if a is None:
         return None
@@ -393,6 +409,61 @@ class Lexicon:
         buf = C.create_string_buffer(need + 1)
         _check(self._L.ssw_alignment_json(*args, buf, need + 1), "ssw_alignment_json")
         return buf.value.decode()
+
+    def word(self, wid: int):
+        w = self._L.ssw_dict_word(self._d, int(wid))
+        return None if w is None else w.decode()
+
+    def word_id(self, word: str) -> int:
+        return int(self._L.ssw_dict_word_id(self._d, word.encode()))
+
+    def first_pass_config(self, **kw) -> FirstPassConfig:
+        cfg = FirstPassConfig()
+        self._L.ssw_first_pass_config_defaults(C.byref(cfg))
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        return cfg
+
+    def first_pass_graph(self, words, cfg=None, max_nodes=1 << 16):
+        """The phone-tree HMMs the first pass searches for one text (host only): a structured
+        array (FP_NODE_DTYPE) and the three beams."""
+        arr = (C.c_char_p * len(words))(*[w.encode() for w in words])
+        nodes = np.zeros(max_nodes, FP_NODE_DTYPE)
+        beams = np.zeros(3, np.int32)
+        n = self._L.ssw_first_pass_graph(self.model._m, self._d,
+                                         None if cfg is None else C.byref(cfg), len(words), arr,
+                                         max_nodes, _ptr(nodes), _ptr(beams))
+        _check(n, "ssw_first_pass_graph")
+        return nodes[:n].copy(), beams
+
+    def first_pass(self, d_senscr, utt_off, texts, cfg=None, max_seg=None, stream=None):
+        """ssw_first_pass_batch: device senone scores of a batch + one word list per utterance
+        -> per utterance a list of (word, start, duration, score), or None when the grammar's
+        final state is not reached."""
+        off = np.ascontiguousarray(utt_off, np.int32)
+        n_utts = len(off) - 1
+        assert len(texts) == n_utts
+        word_off = np.zeros(n_utts + 1, np.int32)
+        word_off[1:] = np.cumsum([len(t) for t in texts])
+        flat = [w.encode() for t in texts for w in t]
+        arr = (C.c_char_p * max(1, len(flat)))(*flat)
+        if max_seg is None:
+            max_seg = 4 * max(len(t) for t in texts) + 8
+        n_seg = np.zeros(n_utts, np.int32)
+        seg = np.zeros((n_utts, max_seg), WORD_SEG_DTYPE)
+        _check(self._L.ssw_first_pass_batch(self.model._m, self._d,
+                                            None if cfg is None else C.byref(cfg),
+                                            _ptr(d_senscr), int(off[-1]), _ptr(off), n_utts,
+                                            _ptr(word_off), arr, max_seg, _ptr(n_seg), _ptr(seg),
+                                            _ptr(stream)), "ssw_first_pass_batch")
+        out = []
+        for u in range(n_utts):
+            if n_seg[u] < 0:
+                out.append(None)
+            else:
+                out.append([(self.word(int(s["wid"])), int(s["start"]), int(s["duration"]),
+                             int(s["score"])) for s in seg[u, :n_seg[u]]])
+        return out
 
     def free(self):
         if getattr(self, "_d", None):

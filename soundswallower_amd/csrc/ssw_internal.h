@@ -69,6 +69,45 @@ void ssw_host_model_free(ssw_host_model_t *h);
 int ssw_host_build_records(ssw_host_model_t *h);
 void ssw_set_error(const char *fmt, ...);
 
+/* Pronunciation dictionary (ssw_lexicon.c) */
+struct ssw_dict_s {
+    int n_words, cap_words;
+    char **word;
+    int16_t **pron; /* CI phone ids */
+    int *pronlen;
+    int *slot;      /* open-addressing hash: word index + 1, 0 = empty */
+    int n_slots;
+    int filler_start; /* first word that came from the filler dictionary (dict_filler_start) */
+    int *alt;         /* dict_nextalt: next alternate pronunciation of the same base word, -1 */
+    int *base;        /* dict_basewid */
+};
+int ssw_dict_find(const struct ssw_dict_s *d, const char *w);
+
+/* First-pass graphs of a batch of texts (ssw_fsg.c), flat arrays the kernel reads.
+ * Node indices, leaf ordinals and states are local to their utterance. */
+typedef struct ssw_fp_graphs_s {
+    int32_t n_utts, n_nodes, n_leaves, n_states, n_in;
+    int32_t *node_off, *leaf_off, *state_off; /* [n_utts + 1] */
+    uint16_t *senid;    /* [n_nodes][4]: three senones, then the transition matrix id */
+    int32_t *pen;       /* [n_nodes] log probability added on entry (logs2prob) */
+    int32_t *parent;    /* [n_nodes] predecessor in the phone tree, -1 for word-initial nodes */
+    uint32_t *info;     /* [n_nodes] bit 0 root, 1 leaf, 2 exit applies to every right context;
+                           8..15 the CI phone shown to neighbours; 16..31 FSG state (roots: the
+                           state they hang off, leaves that are not roots: unused) */
+    uint64_t *ctxt;     /* [n_nodes] roots: left contexts served; leaves: right contexts served */
+    int32_t *leaf_ord;  /* [n_nodes] ordinal among the utterance's leaves, -1 */
+    int32_t *leaf_wid;  /* [n_leaves] dictionary word the leaf ends */
+    int32_t *leaf_to;   /* [n_leaves] FSG state the word leads to */
+    int32_t *leaf_node; /* [n_leaves] the leaf's node */
+    int32_t *in_off;    /* [n_states + 1] leaves entering each state, into in_leaf */
+    int32_t *in_leaf;   /* [n_in] leaf ordinals, by (left-context phone, ordinal) */
+    int32_t beam, pbeam, wbeam;
+} ssw_fp_graphs_t;
+ssw_fp_graphs_t *ssw_fp_graphs_build(const ssw_model_t *m, const struct ssw_dict_s *d,
+                                     const ssw_first_pass_config_t *cfg, int32_t n_utts,
+                                     const int32_t *word_off, const char *const *words);
+void ssw_fp_graphs_free(ssw_fp_graphs_t *g);
+
 #ifdef __cplusplus
 }
 #endif

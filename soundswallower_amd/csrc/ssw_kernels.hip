@@ -21,6 +21,8 @@
  *   ssw_k2_align.inc     viterbi_align_mw_kernel / _reg_kernel / viterbi_align_kernel
  *                        (state_align_search step/finish + hmm_vit_eval_3st_lr,
  *                        src/state_align_search.c:177-268, src/hmm.c:482-567)
+ *   ssw_k5_firstpass.inc first_pass_kernel (fsg_search start/step/finish over the linear
+ *                        grammar's phone trees, src/fsg_search.c:665-925)
  *   ssw_host_*.inc       device model and loaders' upload, batched scoring, alignment, the
  *                        mgau_t / search-module shaped objects, features, device-memory helpers
  */
@@ -56,6 +58,7 @@ namespace {
 #include "ssw_k1b_senone.inc"
 #include "ssw_k4_feat.inc"
 #include "ssw_k2_align.inc"
+#include "ssw_k5_firstpass.inc"
 
 } // namespace
 
@@ -65,4 +68,5 @@ namespace {
 #include "ssw_host_mgau.inc"
 #include "ssw_host_search.inc"
 #include "ssw_host_feat.inc"
+#include "ssw_host_firstpass.inc"
 #include "ssw_host_devmem.inc"

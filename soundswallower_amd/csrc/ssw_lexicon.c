@@ -23,15 +23,6 @@ const ssw_host_model_t *ssw_model_host(const ssw_model_t *m);
 
 enum { POS_INTERNAL = 0, POS_BEGIN = 1, POS_END = 2, POS_SINGLE = 3, POS_UNDEFINED = 4 };
 
-struct ssw_dict_s {
-    int n_words, cap_words;
-    char **word;
-    int16_t **pron; /* CI phone ids */
-    int *pronlen;
-    int *slot;      /* open-addressing hash: word index + 1, 0 = empty */
-    int n_slots;
-};
-
 static uint32_t
 hash_str(const char *s)
 {
@@ -78,18 +69,57 @@ dict_rehash(ssw_dict_t *d)
     }
 }
 
+int
+ssw_dict_find(const ssw_dict_t *d, const char *w)
+{
+    return dict_find(d, w);
+}
+
+/* dict_word2basestr (src/dict.c:400-418): length of the base of "base(...)", or -1 */
+static int
+base_len(const char *w)
+{
+    int len = (int)strlen(w), i;
+    if (len > 0 && w[len - 1] == ')') {
+        for (i = len - 2; i > 0 && w[i] != '('; --i)
+            ;
+        if (i > 0)
+            return i;
+    }
+    return -1;
+}
+
 static int
 dict_add(ssw_dict_t *d, const char *w, const int16_t *pron, int n)
 {
     uint32_t k;
+    int bl = base_len(w), base = -1;
     if (dict_find(d, w) >= 0)
         return 0; /* first definition wins, as dict_add_word refuses duplicates */
+    if (bl > 0) { /* an alternate pronunciation needs its base word first (src/dict.c:92-107) */
+        char *b = strdup(w);
+        b[bl] = '\0';
+        base = dict_find(d, b);
+        free(b);
+        if (base < 0)
+            return 0;
+    }
     if (d->n_words == d->cap_words) {
         d->cap_words = d->cap_words ? d->cap_words * 2 : 4096;
         d->word = (char **)realloc(d->word, sizeof(char *) * (size_t)d->cap_words);
         d->pron = (int16_t **)realloc(d->pron, sizeof(int16_t *) * (size_t)d->cap_words);
         d->pronlen = (int *)realloc(d->pronlen, sizeof(int) * (size_t)d->cap_words);
+        d->alt = (int *)realloc(d->alt, sizeof(int) * (size_t)d->cap_words);
+        d->base = (int *)realloc(d->base, sizeof(int) * (size_t)d->cap_words);
         dict_rehash(d);
+    }
+    if (base >= 0) { /* link into the base word's alt list, newest first */
+        d->base[d->n_words] = base;
+        d->alt[d->n_words] = d->alt[base];
+        d->alt[base] = d->n_words;
+    } else {
+        d->base[d->n_words] = d->n_words;
+        d->alt[d->n_words] = -1;
     }
     d->word[d->n_words] = strdup(w);
     d->pron[d->n_words] = (int16_t *)malloc(sizeof(int16_t) * (size_t)n);
@@ -151,8 +181,12 @@ ssw_dict_load(const ssw_model_t *m, const char *dict_path, const char *filler_pa
     }
     d = (ssw_dict_t *)calloc(1, sizeof(*d));
     d->cap_words = 0;
-    if ((dict_path && dict_read(d, h, dict_path) < 0)
-        || (filler_path && dict_read(d, h, filler_path) < 0)) {
+    if (dict_path && dict_read(d, h, dict_path) < 0) {
+        ssw_dict_free(d);
+        return NULL;
+    }
+    d->filler_start = d->n_words;
+    if (filler_path && dict_read(d, h, filler_path) < 0) {
         ssw_dict_free(d);
         return NULL;
     }
@@ -164,6 +198,8 @@ ssw_dict_load(const ssw_model_t *m, const char *dict_path, const char *filler_pa
             d->word = (char **)calloc(16, sizeof(char *));
             d->pron = (int16_t **)calloc(16, sizeof(int16_t *));
             d->pronlen = (int *)calloc(16, sizeof(int));
+            d->alt = (int *)calloc(16, sizeof(int));
+            d->base = (int *)calloc(16, sizeof(int));
             dict_rehash(d);
         }
         dict_add(d, "<s>", &sil, 1);
@@ -186,6 +222,8 @@ ssw_dict_free(ssw_dict_t *d)
     free(d->word);
     free(d->pron);
     free(d->pronlen);
+    free(d->alt);
+    free(d->base);
     free(d->slot);
     free(d);
 }
@@ -194,6 +232,18 @@ int32_t
 ssw_dict_size(const ssw_dict_t *d)
 {
     return d->n_words;
+}
+
+const char *
+ssw_dict_word(const ssw_dict_t *d, int32_t wid)
+{
+    return (wid >= 0 && wid < d->n_words) ? d->word[wid] : NULL;
+}
+
+int32_t
+ssw_dict_word_id(const ssw_dict_t *d, const char *word)
+{
+    return dict_find(d, word);
 }
 
 int32_t

@@ -1,0 +1,142 @@
+"""First pass of forced alignment on the GPU (ssw_first_pass_batch) against the oracle's
+restatement of fsg_search (oracle/fsg_oracle.py) and against the word segmentations the
+reference itself printed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import soundswallower_amd as ssw
+from soundswallower_amd.synth import lcg_uniform
+from tests.conftest import MODEL_ROOT
+from tests.test_first_pass_oracle import REF_EN, REF_FR, features
+
+pytestmark = pytest.mark.gpu
+
+
+def _lex(model, name):
+    d = os.path.join(MODEL_ROOT, name)
+    return ssw.Lexicon(model, os.path.join(d, "dict.txt"), os.path.join(d, "noisedict.txt"))
+
+
+def _olex(oracle_mod, m, name):
+    from oracle import fsg_oracle as F
+    d = os.path.join(MODEL_ROOT, name)
+    return F, F.Lexicon(m, os.path.join(d, "dict.txt"), os.path.join(d, "noisedict.txt"))
+
+
+def _first_pass(model, lex, senscr_list, texts):
+    """scores (host int16 arrays, one per utterance) -> device -> ssw_first_pass_batch"""
+    off = np.concatenate([[0], np.cumsum([len(s) for s in senscr_list])]).astype(np.int32)
+    d = torch.from_numpy(np.ascontiguousarray(np.concatenate(senscr_list), np.int16)).cuda()
+    return lex.first_pass(d, off, texts)
+
+
+@pytest.mark.parametrize("name,raw,text,ref", [
+    ("en-us", "goforward.raw", "go forward ten meters", REF_EN),
+    ("fr-fr", "goforward_fr.raw", "avance de dix mètres", REF_FR)])
+def test_reference_recordings(oracle_mod, gpu_en, gpu_fr, orc_en, orc_fr, name, raw, text, ref):
+    gpu, orc = (gpu_en, orc_en) if name == "en-us" else (gpu_fr, orc_fr)
+    feats = features(oracle_mod, raw)
+    scr = gpu.score_batch(feats)
+    lex = _lex(gpu, name)
+    seg = _first_pass(gpu, lex, [scr], [text.split()])[0]
+    assert [(w, s, d) for (w, s, d, _) in seg] == ref
+    F, olex = _olex(oracle_mod, orc, name)
+    want = F.first_pass(orc, olex, text.split(), scr)
+    assert [(w, s, s + d - 1, sc) for (w, s, d, sc) in seg] == want
+
+
+def synth_scores(F, orc, olex, words, seed, n_sen, noise_lo=120, noise_hi=400, sil_p=0.5):
+    """Senone scores that follow one path through the text's phone trees: per state a few frames
+    where that state's senone scores near 0 and everything else is `noise`; optional silences
+    between words; alternates picked at random."""
+    lmath = O = None
+    from oracle import oracle as O
+    lmath = O.Logmath(1.0001, 0)
+    arcs = F.build_fsg(olex, words, lmath, F.Config)
+    nodes, roots = F.build_lextree(orc, olex, arcs, 0, 0)
+    rng = np.random.default_rng(seed)
+    path = []
+    def sil_node(s):
+        r = roots[s]
+        while r is not None:
+            if r.leaf and r.link.word == "<sil>":
+                return r
+            r = r.sibling
+    for s in range(len(arcs)):
+        if s == 0 or s == len(arcs) - 1 or rng.random() < sil_p:
+            path.append(sil_node(s))
+        if s == len(arcs) - 1:
+            break
+        cands = []
+        r = roots[s]
+        while r is not None:
+            if not (r.leaf and r.link.filler):
+                cands.append(r)
+            r = r.sibling
+        n = cands[rng.integers(len(cands))]
+        while True:
+            path.append(n)
+            if n.leaf:
+                break
+            kids = []
+            c = n.succ
+            while c is not None:
+                kids.append(c)
+                c = c.sibling
+            n = kids[rng.integers(len(kids))]
+    rows = []
+    for n in path:
+        for st in range(3):
+            for _ in range(int(rng.integers(1, 5))):
+                row = rng.integers(noise_lo, noise_hi, n_sen).astype(np.int16)
+                row[orc.sseq[n.ssid][st]] = rng.integers(0, 30)
+                rows.append(row)
+    return np.stack(rows)
+
+
+def test_synthetic_paths_match_the_oracle(oracle_mod, gpu_en, orc_en):
+    F, olex = _olex(oracle_mod, orc_en, "en-us")
+    lex = _lex(gpu_en, "en-us")
+    vocab = [w for w in olex.order[:olex.filler_start] if "(" not in w]
+    u = lcg_uniform(7, 24 * 10)
+    texts, scores = [], []
+    for t in range(24):
+        n = 1 + int(u[t * 10] * 8)
+        words = [vocab[int(x * len(vocab))] for x in u[t * 10 + 1:t * 10 + 1 + n]]
+        texts.append(words)
+        # a few utterances get noise close to the path: near-ties, wrong turns, failures
+        lo = 120 if t % 4 else 25
+        scores.append(synth_scores(F, orc_en, olex, words, 100 + t, orc_en.n_sen, noise_lo=lo))
+    got = _first_pass(gpu_en, lex, scores, texts)
+    n_ok = 0
+    for t in range(24):
+        want = F.first_pass(orc_en, olex, texts[t], scores[t])
+        if want is None:
+            assert got[t] is None, texts[t]
+            continue
+        n_ok += 1
+        assert got[t] is not None, texts[t]
+        assert [(w, s, s + d - 1, sc) for (w, s, d, sc) in got[t]] == want, texts[t]
+    assert n_ok >= 12
+
+
+def test_wrong_text_and_short_audio(oracle_mod, gpu_en, orc_en):
+    """The same recording against texts it does not contain, and truncated audio: whatever the
+    reference's search does (a forced path, or no path into the final state) must come out."""
+    F, olex = _olex(oracle_mod, orc_en, "en-us")
+    lex = _lex(gpu_en, "en-us")
+    feats = features(oracle_mod, "goforward.raw")
+    scr = gpu_en.score_batch(feats)
+    texts = [t.split() for t in ("go forward", "ten meters go forward", "forward forward forward",
+                                 "a", "go forward ten meters go forward ten meters")]
+    cuts = [len(scr), len(scr), 120, 30, 200]
+    got = _first_pass(gpu_en, lex, [scr[:c] for c in cuts], texts)
+    for t, c, g in zip(texts, cuts, got):
+        want = F.first_pass(orc_en, olex, t, scr[:c])
+        if want is None:
+            assert g is None, t
+        else:
+            assert [(w, s, s + d - 1, sc) for (w, s, d, sc) in g] == want, t
