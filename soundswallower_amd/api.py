@@ -471,3 +471,65 @@ class Lexicon:
             self._d = None
 
     __del__ = free
+
+
+def forced_alignment(model: Model, lex: Lexicon, d_senscr, utt_off, texts, cfg=None, stream=None):
+    """decoder_alignment (src/decoder.c:737-798) for a batch of utterances whose senone scores
+    are in HBM: first pass (which fillers / alternates, word frames) -> alignment_add_word +
+    alignment_populate with those word windows -> state_align_search constrained to them ->
+    alignment_propagate.  Returns one dict per utterance (None where the first pass does not
+    reach the end of the text): words, word_al / phone_al / state_al int32 [n][3] = (start,
+    duration, score), cipid, parent (phone -> word), senid."""
+    off = np.ascontiguousarray(utt_off, np.int32)
+    segs = lex.first_pass(d_senscr, off, texts, cfg=cfg, stream=stream)
+    keep = [u for u, s in enumerate(segs) if s is not None]
+    out = [None] * len(segs)
+    if not keep:
+        return out
+    rows = []
+    for u in keep:
+        words = [w for (w, _, _, _) in segs[u]]
+        rows.append(lex.populate(words, [s for (_, s, _, _) in segs[u]],
+                                 [d for (_, _, d, _) in segs[u]]))
+    sseq = model.table("sseq").reshape(-1, model.n_emit_state)
+    phone_off = np.concatenate([[0], np.cumsum([len(r["ssid"]) for r in rows])]).astype(np.int32)
+    ssid = np.concatenate([r["ssid"] for r in rows])
+    start = np.concatenate([r["start"] for r in rows])
+    dur = np.concatenate([r["duration"] for r in rows])
+    # state_align_search_init, src/state_align_search.c:456-470
+    sf = np.where(start > 0, start, 0).astype(np.int32)
+    ef = np.where(dur > 0, start + dur, INT_MAX).astype(np.int32)
+    state_init = np.stack([np.repeat(start, 3), np.repeat(dur, 3),
+                           np.zeros(3 * len(ssid), np.int32)], 1).astype(np.int32)
+    senid = sseq[ssid].astype(np.uint16)
+    tmat = np.concatenate([r["tmatid"] for r in rows])
+    base = d_senscr.data_ptr() if hasattr(d_senscr, "data_ptr") else int(d_senscr)
+    states = np.zeros((3 * len(ssid), 3), np.int32)
+    status = np.zeros(len(keep), np.int32)
+    # ssw_align_batch wants consecutive utterances: one call per run of surviving ones
+    k0 = 0
+    while k0 < len(keep):
+        k1 = k0 + 1
+        while k1 < len(keep) and keep[k1] == keep[k1 - 1] + 1:
+            k1 += 1
+        u0, u1 = keep[k0], keep[k1 - 1] + 1
+        p0, p1 = phone_off[k0], phone_off[k1]
+        st, stt = model.align_batch(base + int(off[u0]) * model.n_sen * 2, off[u0:u1 + 1] - off[u0],
+                                    phone_off[k0:k1 + 1] - p0, senid[p0:p1], tmat[p0:p1],
+                                    sf[p0:p1], ef[p0:p1], state_init=state_init[3 * p0:3 * p1],
+                                    stream=stream)
+        states[3 * p0:3 * p1] = st
+        status[k0:k1] = stt
+        k0 = k1
+    for k, u in enumerate(keep):
+        if status[k] != 0:
+            continue
+        r = rows[k]
+        st = states[phone_off[k] * 3:phone_off[k + 1] * 3]
+        n_ph = len(r["ssid"])
+        ph = model.propagate(st, np.repeat(np.arange(n_ph), 3), n_ph)
+        words = [w for (w, _, _, _) in segs[u]]
+        out[u] = {"words": words, "word_al": model.propagate(ph, r["parent"], len(words)),
+                  "phone_al": ph, "state_al": st, "cipid": r["cipid"], "parent": r["parent"],
+                  "senid": senid[phone_off[k]:phone_off[k + 1]], "first_pass": segs[u]}
+    return out

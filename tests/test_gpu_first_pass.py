@@ -140,3 +140,38 @@ def test_wrong_text_and_short_audio(oracle_mod, gpu_en, orc_en):
             assert g is None, t
         else:
             assert [(w, s, s + d - 1, sc) for (w, s, d, sc) in g] == want, t
+
+
+def test_text_and_audio_to_the_reference_json(oracle_mod, gpu_en):
+    """decoder_set_align_text + process + decoder_alignment + decoder_result_json, the product's
+    way: cepstra -> device features -> batch scores in HBM -> first pass -> populate with its
+    word windows -> constrained state alignment -> JSON; no reference-derived windows anywhere.
+    The line must be the one the reference printed; a second utterance in
+    the batch (the same audio, a text that cannot be completed) must come back as None without
+    disturbing the first."""
+    from tests.conftest import ROOT
+    from tests.test_lexicon_host import REF_JSON_PREFIX
+    from tests.test_oracle_e2e_goforward import REF_WORDS, _parse_ref
+    pcm = np.fromfile(os.path.join(ROOT, "tests", "golden", "goforward.raw"), dtype="<i2")
+    cep = oracle_mod.fe_mfcc(pcm, nfilt=20, lowerf=130, upperf=3700, lifter=22, remove_noise=True,
+                             transform="dct")         # the MFCC front end is outside the path
+    n = len(cep)
+    feats = gpu_en.feat_batch(np.concatenate([cep, cep[:40]]), utt_off=[0, n, n + 40])
+    d_feats = torch.from_numpy(feats).cuda()
+    d_scr = torch.empty((n + 40, gpu_en.n_sen), dtype=torch.int16, device="cuda")
+    off = np.array([0, n, n + 40], np.int32)
+    gpu_en.score_batch_device(d_feats, n + 40, off, d_scr)
+    torch.cuda.synchronize()
+    lex = _lex(gpu_en, "en-us")
+    texts = ["go forward ten meters".split(), "go forward ten meters".split()]
+    res = ssw.forced_alignment(gpu_en, lex, d_scr, off, texts)
+    assert res[1] is None                      # 40 frames cannot hold the sentence
+    a = res[0]
+    assert a["words"] == [w for (w, _, _, _) in REF_WORDS]
+    assert [tuple(int(x) for x in r) for r in a["word_al"]] == [(s, d, sc) for (_, s, d, sc) in REF_WORDS]
+    ref = _parse_ref()
+    assert [tuple(int(x) for x in r) for r in a["phone_al"]] == [(r[1], r[2], r[3]) for r in ref]
+    line = lex.alignment_json("go forward ten meters", a["words"], a["word_al"], a["cipid"],
+                              a["parent"], a["phone_al"], n_frames=279)
+    assert line.startswith(REF_JSON_PREFIX)
+    lex.free()
