@@ -268,6 +268,33 @@ int ssw_first_pass_batch(ssw_model_t *m, const ssw_dict_t *d, const ssw_first_pa
                          int32_t n_utts, const int32_t *word_off, const char *const *words,
                          int32_t max_seg, int32_t *n_seg, ssw_word_seg_t *seg, void *stream);
 
+/* decoder_alignment (src/decoder.c:737-798) for a batch: first pass, then alignment_add_word
+ * with the first pass's word windows + alignment_populate, the state alignment constrained to
+ * those windows (state_align_search_init / step / finish), alignment_propagate.  The result
+ * holds one alignment_t-shaped record per utterance -- word, phone and state entries with
+ * (start, duration, score) -- read with the accessors below.  Arguments as
+ * ssw_first_pass_batch.  Returns NULL on a call-level error; per-utterance outcomes are in
+ * ssw_alignment_set_status: 0 aligned, 1 the first pass did not reach the end of the text,
+ * 2 the second pass failed ("Failed to reach final state" / "Alignment failed in frame"). */
+typedef struct ssw_alignment_set_s ssw_alignment_set_t;
+ssw_alignment_set_t *ssw_forced_align_batch(ssw_model_t *m, const ssw_dict_t *d,
+                                            const ssw_first_pass_config_t *cfg,
+                                            const int16_t *d_senscr, int32_t n_frames,
+                                            const int32_t *utt_off, int32_t n_utts,
+                                            const int32_t *word_off, const char *const *words,
+                                            void *stream);
+int32_t ssw_alignment_set_status(const ssw_alignment_set_t *a, int32_t utt);
+/* each returns the number of entries and points the outputs (any may be NULL) at arrays owned
+ * by the set: words -> dictionary ids; phones -> CI phone id and parent word index;
+ * states -> senone id and parent phone = index / 3 */
+int32_t ssw_alignment_set_words(const ssw_alignment_set_t *a, int32_t utt, const int32_t **wid,
+                                const ssw_align_entry_t **al);
+int32_t ssw_alignment_set_phones(const ssw_alignment_set_t *a, int32_t utt, const int32_t **cipid,
+                                 const int32_t **parent, const ssw_align_entry_t **al);
+int32_t ssw_alignment_set_states(const ssw_alignment_set_t *a, int32_t utt,
+                                 const uint16_t **senid, const ssw_align_entry_t **al);
+void ssw_alignment_set_free(ssw_alignment_set_t *a);
+
 /* The graph ssw_first_pass_batch searches for one text, node by node (host only, works without
  * a device): the phone-tree HMMs of fsg_lextree_init with their entry penalty, predecessor,
  * FSG state and context sets.  flags: 1 word-initial, 2 word-final, 4 exit valid for every

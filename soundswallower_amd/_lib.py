@@ -124,6 +124,17 @@ def lib() -> C.CDLL:
     L.ssw_first_pass_graph.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp]
     L.ssw_first_pass_batch.restype = C.c_int
     L.ssw_first_pass_batch.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp]
+    L.ssw_forced_align_batch.restype = vp
+    L.ssw_forced_align_batch.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp]
+    L.ssw_alignment_set_status.restype = i32
+    L.ssw_alignment_set_status.argtypes = [vp, i32]
+    for fn in (L.ssw_alignment_set_words, L.ssw_alignment_set_states):
+        fn.restype = i32
+        fn.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
+    L.ssw_alignment_set_phones.restype = i32
+    L.ssw_alignment_set_phones.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.ssw_alignment_set_free.argtypes = [vp]
+    L.ssw_alignment_set_free.restype = None
     L.ssw_ciphone_name.restype = C.c_char_p
     L.ssw_ciphone_name.argtypes = [vp, i32]
     L.ssw_phone_id_nearest.restype = i32

@@ -440,6 +440,18 @@ class Lexicon:
         """ssw_first_pass_batch: device senone scores of a batch + one word list per utterance
         -> per utterance a list of (word, start, duration, score), or None when the grammar's
         final state is not reached."""
+        n_seg, seg = self.first_pass_raw(d_senscr, utt_off, texts, cfg, max_seg, stream)
+        out = []
+        for u in range(len(n_seg)):
+            if n_seg[u] < 0:
+                out.append(None)
+            else:
+                out.append([(self.word(int(s["wid"])), int(s["start"]), int(s["duration"]),
+                             int(s["score"])) for s in seg[u, :n_seg[u]]])
+        return out
+
+    def first_pass_raw(self, d_senscr, utt_off, texts, cfg=None, max_seg=None, stream=None):
+        """The C call alone: (n_seg int32 [n_utts], seg WORD_SEG_DTYPE [n_utts][max_seg])."""
         off = np.ascontiguousarray(utt_off, np.int32)
         n_utts = len(off) - 1
         assert len(texts) == n_utts
@@ -456,14 +468,7 @@ class Lexicon:
                                             _ptr(d_senscr), int(off[-1]), _ptr(off), n_utts,
                                             _ptr(word_off), arr, max_seg, _ptr(n_seg), _ptr(seg),
                                             _ptr(stream)), "ssw_first_pass_batch")
-        out = []
-        for u in range(n_utts):
-            if n_seg[u] < 0:
-                out.append(None)
-            else:
-                out.append([(self.word(int(s["wid"])), int(s["start"]), int(s["duration"]),
-                             int(s["score"])) for s in seg[u, :n_seg[u]]])
-        return out
+        return n_seg, seg
 
     def free(self):
         if getattr(self, "_d", None):
@@ -473,63 +478,72 @@ class Lexicon:
     __del__ = free
 
 
-def forced_alignment(model: Model, lex: Lexicon, d_senscr, utt_off, texts, cfg=None, stream=None):
-    """decoder_alignment (src/decoder.c:737-798) for a batch of utterances whose senone scores
-    are in HBM: first pass (which fillers / alternates, word frames) -> alignment_add_word +
-    alignment_populate with those word windows -> state_align_search constrained to them ->
-    alignment_propagate.  Returns one dict per utterance (None where the first pass does not
-    reach the end of the text): words, word_al / phone_al / state_al int32 [n][3] = (start,
-    duration, score), cipid, parent (phone -> word), senid."""
+def _view(ptr, n, dtype, cols=None):
+    if n <= 0 or not ptr:
+        return np.zeros((0, cols) if cols else 0, dtype)
+    count = n * (cols or 1)
+    buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=count).copy()
+    return arr.reshape(n, cols) if cols else arr
+
+
+class AlignmentSet:
+    """ssw_alignment_set_t: the alignment_t-shaped result of ssw_forced_align_batch."""
+
+    def __init__(self, lib, handle, lex):
+        self._L, self._a, self._lex = lib, handle, lex
+
+    def status(self, u):
+        return int(self._L.ssw_alignment_set_status(self._a, u))
+
+    def utterance(self, u):
+        """None unless status 0; else dict(words, word_al, cipid, parent, phone_al, senid,
+        state_al) with *_al int32 [n][3] = (start, duration, score)."""
+        if self.status(u) != 0:
+            return None
+        p1, p2, p3 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n = self._L.ssw_alignment_set_words(self._a, u, C.byref(p1), C.byref(p2))
+        wid = _view(p1, n, np.int32)
+        word_al = _view(p2, n, np.int32, 3)
+        n = self._L.ssw_alignment_set_phones(self._a, u, C.byref(p1), C.byref(p2), C.byref(p3))
+        cipid, parent, phone_al = _view(p1, n, np.int32), _view(p2, n, np.int32), _view(p3, n, np.int32, 3)
+        n = self._L.ssw_alignment_set_states(self._a, u, C.byref(p1), C.byref(p2))
+        senid, state_al = _view(p1, n, np.uint16), _view(p2, n, np.int32, 3)
+        return {"wid": wid, "words": [self._lex.word(int(w)) for w in wid], "word_al": word_al,
+                "cipid": cipid, "parent": parent, "phone_al": phone_al,
+                "senid": senid.reshape(-1, 3), "state_al": state_al}
+
+    def free(self):
+        if self._a:
+            self._L.ssw_alignment_set_free(self._a)
+            self._a = None
+
+    __del__ = free
+
+
+def forced_align_batch(model: Model, lex: Lexicon, d_senscr, utt_off, texts, cfg=None,
+                       stream=None) -> AlignmentSet:
+    """ssw_forced_align_batch: decoder_alignment (src/decoder.c:737-798) for a batch of
+    utterances whose senone scores are in HBM -- first pass, populate with its word windows,
+    constrained state alignment, propagate -- in one C call."""
     off = np.ascontiguousarray(utt_off, np.int32)
-    segs = lex.first_pass(d_senscr, off, texts, cfg=cfg, stream=stream)
-    keep = [u for u, s in enumerate(segs) if s is not None]
-    out = [None] * len(segs)
-    if not keep:
-        return out
-    rows = []
-    for u in keep:
-        words = [w for (w, _, _, _) in segs[u]]
-        rows.append(lex.populate(words, [s for (_, s, _, _) in segs[u]],
-                                 [d for (_, _, d, _) in segs[u]]))
-    sseq = model.table("sseq").reshape(-1, model.n_emit_state)
-    phone_off = np.concatenate([[0], np.cumsum([len(r["ssid"]) for r in rows])]).astype(np.int32)
-    ssid = np.concatenate([r["ssid"] for r in rows])
-    start = np.concatenate([r["start"] for r in rows])
-    dur = np.concatenate([r["duration"] for r in rows])
-    # state_align_search_init, src/state_align_search.c:456-470
-    sf = np.where(start > 0, start, 0).astype(np.int32)
-    ef = np.where(dur > 0, start + dur, INT_MAX).astype(np.int32)
-    state_init = np.stack([np.repeat(start, 3), np.repeat(dur, 3),
-                           np.zeros(3 * len(ssid), np.int32)], 1).astype(np.int32)
-    senid = sseq[ssid].astype(np.uint16)
-    tmat = np.concatenate([r["tmatid"] for r in rows])
-    base = d_senscr.data_ptr() if hasattr(d_senscr, "data_ptr") else int(d_senscr)
-    states = np.zeros((3 * len(ssid), 3), np.int32)
-    status = np.zeros(len(keep), np.int32)
-    # ssw_align_batch wants consecutive utterances: one call per run of surviving ones
-    k0 = 0
-    while k0 < len(keep):
-        k1 = k0 + 1
-        while k1 < len(keep) and keep[k1] == keep[k1 - 1] + 1:
-            k1 += 1
-        u0, u1 = keep[k0], keep[k1 - 1] + 1
-        p0, p1 = phone_off[k0], phone_off[k1]
-        st, stt = model.align_batch(base + int(off[u0]) * model.n_sen * 2, off[u0:u1 + 1] - off[u0],
-                                    phone_off[k0:k1 + 1] - p0, senid[p0:p1], tmat[p0:p1],
-                                    sf[p0:p1], ef[p0:p1], state_init=state_init[3 * p0:3 * p1],
-                                    stream=stream)
-        states[3 * p0:3 * p1] = st
-        status[k0:k1] = stt
-        k0 = k1
-    for k, u in enumerate(keep):
-        if status[k] != 0:
-            continue
-        r = rows[k]
-        st = states[phone_off[k] * 3:phone_off[k + 1] * 3]
-        n_ph = len(r["ssid"])
-        ph = model.propagate(st, np.repeat(np.arange(n_ph), 3), n_ph)
-        words = [w for (w, _, _, _) in segs[u]]
-        out[u] = {"words": words, "word_al": model.propagate(ph, r["parent"], len(words)),
-                  "phone_al": ph, "state_al": st, "cipid": r["cipid"], "parent": r["parent"],
-                  "senid": senid[phone_off[k]:phone_off[k + 1]], "first_pass": segs[u]}
+    n_utts = len(off) - 1
+    word_off = np.zeros(n_utts + 1, np.int32)
+    word_off[1:] = np.cumsum([len(t) for t in texts])
+    flat = [w.encode() for t in texts for w in t]
+    arr = (C.c_char_p * max(1, len(flat)))(*flat)
+    L = _lib.lib()
+    h = L.ssw_forced_align_batch(model._m, lex._d, None if cfg is None else C.byref(cfg),
+                                 _ptr(d_senscr), int(off[-1]), _ptr(off), n_utts, _ptr(word_off),
+                                 arr, _ptr(stream))
+    if not h:
+        raise SswError("ssw_forced_align_batch: " + _lib.last_error())
+    return AlignmentSet(L, h, lex)
+
+
+def forced_alignment(model: Model, lex: Lexicon, d_senscr, utt_off, texts, cfg=None, stream=None):
+    """forced_align_batch, unpacked: one dict per utterance, None where it could not be aligned."""
+    s = forced_align_batch(model, lex, d_senscr, utt_off, texts, cfg=cfg, stream=stream)
+    out = [s.utterance(u) for u in range(len(texts))]
+    s.free()
     return out

@@ -54,6 +54,13 @@ ilog0(double base, double p)
     return (int32_t)(log(p) * (1.0 / log(base)));
 }
 
+static int
+cmp_u64(const void *a, const void *b)
+{
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return (x > y) - (x < y);
+}
+
 typedef struct {
     int word;     /* dictionary id */
     int to;       /* destination state */
@@ -361,20 +368,26 @@ build_one(builder_t *b, const ssw_model_t *m, const ssw_host_model_t *h, const s
     /* leaves entering each state, by (left-context phone they present, ordinal) */
     {
         const int nl = g->n_leaves - leaf_base;
-        int st, ci;
-        if (grow((void **)&g->in_off, &b->cap_states, g->n_states + n_state + 1, sizeof(int32_t)) < 0
-            || grow((void **)&g->in_leaf, &b->cap_in, g->n_in + nl, sizeof(int32_t)) < 0)
+        uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(nl ? nl : 1));
+        int st, k2 = 0;
+        if (keys == NULL
+            || grow((void **)&g->in_off, &b->cap_states, g->n_states + n_state + 1, sizeof(int32_t)) < 0
+            || grow((void **)&g->in_leaf, &b->cap_in, g->n_in + nl, sizeof(int32_t)) < 0) {
+            free(keys);
             goto oom;
+        }
+        for (i = 0; i < nl; ++i) {
+            const int node = base + g->leaf_node[leaf_base + i];
+            keys[i] = ((uint64_t)g->leaf_to[leaf_base + i] << 40)
+                | ((uint64_t)((g->info[node] >> 8) & 0xff) << 32) | (uint64_t)i;
+        }
+        qsort(keys, (size_t)nl, sizeof(uint64_t), cmp_u64);
         for (st = 0; st < n_state; ++st) {
             g->in_off[g->n_states + st] = g->n_in;
-            for (ci = 0; ci < h->n_ciphone; ++ci)
-                for (i = base; i < g->n_nodes; ++i) {
-                    int lo = g->leaf_ord[i];
-                    if (lo >= 0 && g->leaf_to[leaf_base + lo] == st
-                        && (int)((g->info[i] >> 8) & 0xff) == ci)
-                        g->in_leaf[g->n_in++] = lo;
-                }
+            while (k2 < nl && (int)(keys[k2] >> 40) == st)
+                g->in_leaf[g->n_in++] = (int32_t)(keys[k2++] & 0xffffffffu);
         }
+        free(keys);
         g->n_states += n_state;
         g->in_off[g->n_states] = g->n_in;
     }

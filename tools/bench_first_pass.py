@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""First pass + second pass of forced alignment from TEXT, timed on one MI355X.
+
+N utterances x F frames; every utterance is a text of W random dictionary words.  The audio is
+synthetic but follows the text: for every HMM state along one path through the text's phone
+trees the frame's features sit on the mean of the best-weighted Gaussian of that state's senone
+(per stream), plus noise -- so the first pass has something to find, as it would on speech.
+Timed: senone scoring; the first pass alone (ssw_first_pass_batch: graphs built on the host,
+search on the GPU); and decoder_alignment as a whole (first pass + populate + constrained state
+alignment + propagate, soundswallower_amd.forced_alignment).
+Prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import soundswallower_amd as ssw  # noqa: E402
+from soundswallower_amd import _lib  # noqa: E402
+from soundswallower_amd.synth import lcg_uniform, read_raw_means  # noqa: E402
+
+
+def path_through(lex, nodes, n_words, rng):
+    """one node sequence <sil> w1 ... wN <sil> through the graph of ssw_first_pass_graph"""
+    kids = {}
+    for i, n in enumerate(nodes):
+        if n["parent"] >= 0:
+            kids.setdefault(int(n["parent"]), []).append(i)
+    filler = [bool(n["flags"] & 2) and lex.word(int(n["wid"])).startswith(("<", "["))
+              for n in nodes]
+    def sil(state):
+        for i, n in enumerate(nodes):
+            if filler[i] and n["state"] == state and lex.word(int(n["wid"])) == "<sil>":
+                return i
+    path = [sil(0)]
+    for s in range(n_words):
+        roots = [i for i, n in enumerate(nodes)
+                 if (n["flags"] & 1) and n["state"] == s and not filler[i]]
+        i = roots[rng.integers(len(roots))]
+        while True:
+            path.append(i)
+            if nodes[i]["flags"] & 2:
+                break
+            i = kids[i][rng.integers(len(kids[i]))]
+    path.append(sil(n_words))
+    return path
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--utts", type=int, default=256)
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--words", type=int, default=25)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--noise", type=float, default=0.3)
+    a = ap.parse_args()
+    import torch
+    _lib.build()
+    mdir = ssw.model_dir("en-us")
+    m = ssw.Model(mdir)
+    lex = ssw.Lexicon(m, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
+    means = read_raw_means(mdir)                                  # [cb][feat][density][13]
+    mixw = m.table("ptm_mixw").reshape(m.n_feat, m.n_density, m.n_sen)
+    sen2cb = m.table("sen2cb")
+    best_d = mixw.argmin(axis=1)                                  # [feat][sen]
+    sen_mean = np.concatenate([means[sen2cb, f, best_d[f]] for f in range(m.n_feat)], axis=1)
+    n_dict = len(lex)
+    vocab = []
+    u = lcg_uniform(4242, 4 * a.utts * a.words)
+    k = 0
+    texts, feats, n_nodes = [], [], []
+    rng = np.random.default_rng(1)
+    for t in range(a.utts):
+        while True:
+            words = []
+            while len(words) < a.words:
+                w = lex.word(int(u[k % len(u)] * n_dict))
+                k += 1
+                if w and "(" not in w and not w.startswith(("<", "[")):
+                    words.append(w)
+            nodes, _ = lex.first_pass_graph(words)
+            path = path_through(lex, nodes, a.words, rng)
+            if 3 * len(path) <= a.frames:
+                break
+        states = np.array([s for i in path for s in nodes[i]["senid"]])
+        per = np.full(len(states), a.frames // len(states))
+        per[-3:] += (a.frames - per.sum() + 2) // 3
+        per[-1] += a.frames - per.sum()
+        sen = np.repeat(states, per)
+        x = sen_mean[sen] + rng.standard_normal((a.frames, sen_mean.shape[1])).astype(np.float32) * a.noise
+        texts.append(words)
+        feats.append(x.astype(np.float32))
+        n_nodes.append(len(nodes))
+    feats = np.concatenate(feats)
+    off = (np.arange(a.utts + 1) * a.frames).astype(np.int32)
+    d_feats = torch.from_numpy(feats).cuda()
+    d_scr = torch.empty((len(feats), m.n_sen), dtype=torch.int16, device="cuda")
+    best = None
+    for _ in range(a.reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.score_batch_device(d_feats, len(feats), off, d_scr)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        lex.first_pass_raw(d_scr, off, texts)
+        t2 = time.perf_counter()
+        aset = ssw.forced_align_batch(m, lex, d_scr, off, texts)   # first pass again + the rest
+        t3 = time.perf_counter()
+        res = [aset.utterance(k) for k in range(a.utts)]
+        aset.free()
+        cur = {"score_s": t1 - t0, "first_pass_s": t2 - t1, "alignment_s": t3 - t2}
+        if best is None or cur["score_s"] + cur["alignment_s"] < best["score_s"] + best["alignment_s"]:
+            best = cur
+    segs = lex.first_pass(d_scr, off, texts)
+    done = [s for s in segs if s is not None]
+    same_words = sum(1 for s, t in zip(segs, texts) if s is not None and
+                     [w.split("(")[0] for (w, _, _, _) in s if not w.startswith(("<", "["))] == t)
+    aligned = sum(1 for r in res if r is not None)
+    audio_s = a.utts * a.frames / 100.0
+    wall = best["score_s"] + best["alignment_s"]
+    print(json.dumps({
+        "workload": f"{a.utts} utterances x {a.frames} frames, texts of {a.words} words, en-us; "
+                    f"synthetic audio following the text",
+        "nodes_per_text": float(np.mean(n_nodes)),
+        "score_ms": best["score_s"] * 1e3, "first_pass_ms": best["first_pass_s"] * 1e3,
+        "decoder_alignment_ms": best["alignment_s"] * 1e3,
+        "first_pass_completed": len(done), "first_pass_words_equal_text": same_words,
+        "aligned": aligned, "n_utts": a.utts,
+        "text_to_alignment_rtf": wall / audio_s,
+        "first_pass_utt_frames_per_s": a.utts * a.frames / best["first_pass_s"],
+    }))
+
+
+if __name__ == "__main__":
+    main()
