@@ -175,3 +175,23 @@ def test_text_and_audio_to_the_reference_json(oracle_mod, gpu_en):
                               a["parent"], a["phone_al"], n_frames=279)
     assert line.startswith(REF_JSON_PREFIX)
     lex.free()
+
+
+def test_long_texts_use_the_wider_kernels(oracle_mod, gpu_en, orc_en):
+    """Texts of 60 and 150 words: more than 512 / 1024 phone-tree HMMs, i.e. 4 and 8 nodes per
+    thread; same results as the oracle."""
+    F, olex = _olex(oracle_mod, orc_en, "en-us")
+    lex = _lex(gpu_en, "en-us")
+    vocab = [w for w in olex.order[:olex.filler_start] if "(" not in w]
+    u = lcg_uniform(31, 400)
+    texts = [[vocab[int(x * len(vocab))] for x in u[:60]],
+             [vocab[int(x * len(vocab))] for x in u[100:250]]]
+    for t in texts:
+        assert len(lex.first_pass_graph(t)[0]) > (512 if len(t) == 60 else 1024)
+    scores = [synth_scores(F, orc_en, olex, t, 5 + i, orc_en.n_sen, sil_p=0.2)
+              for i, t in enumerate(texts)]
+    got = _first_pass(gpu_en, lex, scores, texts)
+    for t, sc, g in zip(texts, scores, got):
+        want = F.first_pass(orc_en, olex, t, sc)
+        assert want is not None and g is not None
+        assert [(w, s, s + d - 1, x) for (w, s, d, x) in g] == want
