@@ -22,6 +22,7 @@
 #include "ssw_internal.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -409,8 +410,8 @@ bad:
     return -1;
 }
 
-ssw_fp_graphs_t *
-ssw_fp_graphs_build(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_pass_config_t *cfg_in,
+static ssw_fp_graphs_t *
+graphs_build_serial(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_pass_config_t *cfg_in,
                     int32_t n_utts, const int32_t *word_off, const char *const *words)
 {
     const ssw_host_model_t *h = ssw_model_host(m);
@@ -452,8 +453,8 @@ ssw_fp_graphs_build(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_p
         g->node_off[u] = g->n_nodes;
         g->leaf_off[u] = g->n_leaves;
         g->state_off[u] = g->n_states;
-        if (build_one(&b, m, h, d, &cfg, word_off[u + 1] - word_off[u], words + word_off[u], wip,
-                      pip, logsil, logfil) < 0) {
+        if (build_one(&b, m, h, d, &cfg, word_off[u + 1] - word_off[u],
+                      words + (word_off[u] - word_off[0]), wip, pip, logsil, logfil) < 0) {
             ssw_fp_graphs_free(g);
             return NULL;
         }
@@ -461,6 +462,161 @@ ssw_fp_graphs_build(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_p
     g->node_off[n_utts] = g->n_nodes;
     g->leaf_off[n_utts] = g->n_leaves;
     g->state_off[n_utts] = g->n_states;
+    return g;
+}
+
+/* Texts are independent: large batches are built by a few threads, each over a contiguous
+ * range of utterances, and the pieces are concatenated (indices are local to an utterance;
+ * only the offsets tables need rebasing). */
+typedef struct {
+    const ssw_model_t *m;
+    const ssw_dict_t *d;
+    const ssw_first_pass_config_t *cfg;
+    int32_t n_utts;
+    const int32_t *word_off;
+    const char *const *words;
+    ssw_fp_graphs_t *out;
+    char err[512]; /* the error text is thread-local: carried back by hand */
+} build_job_t;
+
+static void *
+build_thread(void *arg)
+{
+    build_job_t *j = (build_job_t *)arg;
+    j->out = graphs_build_serial(j->m, j->d, j->cfg, j->n_utts, j->word_off, j->words);
+    j->err[0] = '\0';
+    if (j->out == NULL) {
+        strncpy(j->err, ssw_last_error(), sizeof(j->err) - 1);
+        j->err[sizeof(j->err) - 1] = '\0';
+    }
+    return NULL;
+}
+
+#define CAT(field, count_field, type)                                                        \
+    do {                                                                                     \
+        g->field = (type *)malloc(sizeof(type) * (size_t)(total.count_field ? total.count_field : 1)); \
+        if (g->field == NULL)                                                                \
+            ok = 0;                                                                          \
+        else {                                                                               \
+            size_t at = 0;                                                                   \
+            for (t = 0; t < n_thr; ++t) {                                                    \
+                memcpy(g->field + at, job[t].out->field, sizeof(type) * (size_t)job[t].out->count_field); \
+                at += (size_t)job[t].out->count_field;                                       \
+            }                                                                                \
+        }                                                                                    \
+    } while (0)
+
+ssw_fp_graphs_t *
+ssw_fp_graphs_build(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_pass_config_t *cfg,
+                    int32_t n_utts, const int32_t *word_off, const char *const *words)
+{
+    enum { MAX_THR = 8, MIN_PER_THR = 16 };
+    build_job_t job[MAX_THR];
+    pthread_t thr[MAX_THR];
+    int started[MAX_THR];
+    ssw_fp_graphs_t *g, total;
+    int n_thr = n_utts / MIN_PER_THR, t, ok = 1, u;
+    if (n_thr > MAX_THR)
+        n_thr = MAX_THR;
+    if (n_thr < 2)
+        return graphs_build_serial(m, d, cfg, n_utts, word_off, words);
+    for (t = 0; t < n_thr; ++t) {
+        const int u0 = (int)((long long)n_utts * t / n_thr), u1 = (int)((long long)n_utts * (t + 1) / n_thr);
+        job[t].m = m;
+        job[t].d = d;
+        job[t].cfg = cfg;
+        job[t].n_utts = u1 - u0;
+        job[t].word_off = word_off + u0;
+        job[t].words = words + word_off[u0];
+        job[t].out = NULL;
+        started[t] = pthread_create(&thr[t], NULL, build_thread, &job[t]) == 0;
+        if (!started[t])
+            build_thread(&job[t]);
+    }
+    memset(&total, 0, sizeof(total));
+    for (t = 0; t < n_thr; ++t) {
+        if (started[t])
+            pthread_join(thr[t], NULL);
+        if (job[t].out == NULL) {
+            if (ok)
+                ssw_set_error("%s", job[t].err);
+            ok = 0;
+        } else {
+            total.n_nodes += job[t].out->n_nodes;
+            total.n_leaves += job[t].out->n_leaves;
+            total.n_states += job[t].out->n_states;
+            total.n_in += job[t].out->n_in;
+        }
+    }
+    g = ok ? (ssw_fp_graphs_t *)calloc(1, sizeof(*g)) : NULL;
+    if (g) {
+        g->n_utts = n_utts;
+        g->n_nodes = total.n_nodes;
+        g->n_leaves = total.n_leaves;
+        g->n_states = total.n_states;
+        g->n_in = total.n_in;
+        g->beam = job[0].out->beam;
+        g->pbeam = job[0].out->pbeam;
+        g->wbeam = job[0].out->wbeam;
+        g->node_off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n_utts + 1));
+        g->leaf_off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n_utts + 1));
+        g->state_off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n_utts + 1));
+        g->in_off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)total.n_states + 1));
+        if (!g->node_off || !g->leaf_off || !g->state_off || !g->in_off)
+            ok = 0;
+        else {
+            int nb = 0, lb = 0, sb = 0, ib = 0;
+            u = 0;
+            for (t = 0; t < n_thr; ++t) {
+                const ssw_fp_graphs_t *p = job[t].out;
+                int k;
+                for (k = 0; k < p->n_utts; ++k, ++u) {
+                    g->node_off[u] = nb + p->node_off[k];
+                    g->leaf_off[u] = lb + p->leaf_off[k];
+                    g->state_off[u] = sb + p->state_off[k];
+                }
+                for (k = 0; k < p->n_states; ++k)
+                    g->in_off[sb + k] = ib + p->in_off[k];
+                nb += p->n_nodes;
+                lb += p->n_leaves;
+                sb += p->n_states;
+                ib += p->n_in;
+            }
+            g->node_off[n_utts] = nb;
+            g->leaf_off[n_utts] = lb;
+            g->state_off[n_utts] = sb;
+            g->in_off[sb] = ib;
+        }
+        if (ok) {
+            g->senid = (uint16_t *)malloc(sizeof(uint16_t) * 4 * (size_t)(total.n_nodes ? total.n_nodes : 1));
+            if (g->senid == NULL)
+                ok = 0;
+            else {
+                size_t at = 0;
+                for (t = 0; t < n_thr; ++t) {
+                    memcpy(g->senid + at, job[t].out->senid, sizeof(uint16_t) * 4 * (size_t)job[t].out->n_nodes);
+                    at += 4 * (size_t)job[t].out->n_nodes;
+                }
+            }
+            CAT(pen, n_nodes, int32_t);
+            CAT(parent, n_nodes, int32_t);
+            CAT(info, n_nodes, uint32_t);
+            CAT(ctxt, n_nodes, uint64_t);
+            CAT(leaf_ord, n_nodes, int32_t);
+            CAT(leaf_wid, n_leaves, int32_t);
+            CAT(leaf_to, n_leaves, int32_t);
+            CAT(leaf_node, n_leaves, int32_t);
+            CAT(in_leaf, n_in, int32_t);
+        }
+    }
+    for (t = 0; t < n_thr; ++t)
+        ssw_fp_graphs_free(job[t].out);
+    if (!ok) {
+        if (g)
+            ssw_set_error("out of memory building the first-pass graphs");
+        ssw_fp_graphs_free(g);
+        return NULL;
+    }
     return g;
 }
 

@@ -195,3 +195,23 @@ def test_long_texts_use_the_wider_kernels(oracle_mod, gpu_en, orc_en):
         want = F.first_pass(orc_en, olex, t, sc)
         assert want is not None and g is not None
         assert [(w, s, s + d - 1, x) for (w, s, d, x) in g] == want
+
+
+def test_large_batch_equals_one_by_one(oracle_mod, gpu_en, orc_en):
+    """64 utterances in one call (graphs built by several host threads and concatenated) give
+    what 64 single-utterance calls give; an unknown word anywhere fails the call with the
+    reference's message."""
+    F, olex = _olex(oracle_mod, orc_en, "en-us")
+    lex = _lex(gpu_en, "en-us")
+    vocab = [w for w in olex.order[:olex.filler_start] if "(" not in w]
+    u = lcg_uniform(77, 64 * 6)
+    texts = [[vocab[int(x * len(vocab))] for x in u[t * 6:t * 6 + 1 + t % 5]] for t in range(64)]
+    scores = [synth_scores(F, orc_en, olex, t, 900 + i, orc_en.n_sen) for i, t in enumerate(texts)]
+    got = _first_pass(gpu_en, lex, scores, texts)
+    for i in range(64):
+        assert got[i] == _first_pass(gpu_en, lex, [scores[i]], [texts[i]])[0], i
+    assert sum(g is not None for g in got) > 48
+    bad = [list(t) for t in texts]
+    bad[50] = bad[50] + ["qqqqq"]
+    with pytest.raises(ssw.SswError, match="Unknown word qqqqq"):
+        _first_pass(gpu_en, lex, scores, bad)
