@@ -123,6 +123,66 @@ gpu_second_pass(decoder_t *d, alignment_t *al, int n_frames)
     return rv;
 }
 
+/* both passes on the GPU for one decoder -- what
+ * decoder_set_align_text + the first pass + decoder_alignment (src/decoder.c:686-798) do,
+ * starting from the features acmod has buffered.  gpu_dict is ssw_dict_load() of the same
+ * dictionary files.  Returns a filled alignment_t (caller frees) or NULL. */
+alignment_t *
+gpu_text_alignment(decoder_t *d, ssw_dict_t *gpu_dict, const char *const *words, int n_words)
+{
+    acmod_t *acmod = d->acmod;
+    const int n_frames = acmod->n_feat_frame, n_sen = bin_mdef_n_sen(acmod->mdef);
+    const int32 utt_off[2] = { 0, n_frames }, word_off[2] = { 0, n_words };
+    const size_t feat_bytes = (size_t)n_frames * 39 * sizeof(float);
+    float *d_feat = ssw_device_malloc(feat_bytes);
+    int16 *d_scr = ssw_device_malloc((size_t)n_frames * n_sen * sizeof(int16));
+    ssw_alignment_set_t *set = NULL;
+    alignment_t *al = NULL;
+    const int32 *wid;
+    const ssw_align_entry_t *wal, *sal;
+    alignment_iter_t *it;
+    int i, n;
+
+    if (d_feat == NULL || d_scr == NULL
+        || ssw_memcpy_h2d(d_feat, acmod->feat_buf[0][0], feat_bytes) < 0
+        || ssw_score_batch(gpu_model, SSW_SCORER_PTM, d_feat, n_frames, utt_off, 1, d_scr, NULL) < 0
+        || ssw_device_synchronize() < 0
+        || (set = ssw_forced_align_batch(gpu_model, gpu_dict, NULL, d_scr, n_frames, utt_off, 1,
+                                         word_off, words, NULL)) == NULL) {
+        E_ERROR("%s\n", ssw_last_error());
+        goto done;
+    }
+    if (ssw_alignment_set_status(set, 0) != 0) {
+        E_ERROR("Final result does not match the grammar, or the alignment failed\n");
+        goto done;
+    }
+    /* the words the first pass found (fillers and alternates included), as decoder_alignment
+     * adds them from the seg_iter (src/decoder.c:758-768) */
+    al = alignment_init(d->d2p);
+    n = ssw_alignment_set_words(set, 0, &wid, &wal);
+    for (i = 0; i < n; ++i)
+        alignment_add_word(al, dict_wordid(d->dict, ssw_dict_word(gpu_dict, wid[i])),
+                           wal[i].start, wal[i].duration);
+    if (alignment_populate(al) < 0) {
+        alignment_free(al);
+        al = NULL;
+        goto done;
+    }
+    ssw_alignment_set_states(set, 0, NULL, &sal);
+    for (i = 0, it = alignment_states(al); it; it = alignment_iter_next(it), ++i) {
+        alignment_entry_t *e = alignment_iter_get(it);
+        e->start = sal[i].start;
+        e->duration = sal[i].duration;
+        e->score = sal[i].score;
+    }
+    alignment_propagate(al);
+done:
+    ssw_alignment_set_free(set);
+    ssw_device_free(d_feat);
+    ssw_device_free(d_scr);
+    return al;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* INTEGRATION.md section 2, vtable level: a search module decoder_alignment() can drive   */
 /* unchanged.  Replace its call                                                           */
