@@ -261,6 +261,12 @@ def main():
     }
     if not args.no_align and world == 1 and args.model == "en-us":
         out["align"] = align_config3(ssw, model, means, torch)
+        # the same job from TEXT: first pass (which fillers / alternates, word frames) + the
+        # rest of decoder_alignment, tools/bench_first_pass.py
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import bench_first_pass
+        lex = ssw.Lexicon(model, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
+        out["text_align"] = bench_first_pass.run(ssw, model, lex, torch)
     if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(mdir, feats, utt_off)
     print(json.dumps(out), flush=True)

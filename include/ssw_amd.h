@@ -298,7 +298,8 @@ void ssw_alignment_set_free(ssw_alignment_set_t *a);
 /* The graph ssw_first_pass_batch searches for one text, node by node (host only, works without
  * a device): the phone-tree HMMs of fsg_lextree_init with their entry penalty, predecessor,
  * FSG state and context sets.  flags: 1 word-initial, 2 word-final, 4 exit valid for every
- * right context.  beams[3] receives beam, pbeam, wbeam in score units.  Returns the node
+ * right context, 8 / 16 / 32 member / first / last of a group of word-final HMMs that can never
+ * differ (alternates pronounced alike).  beams[3] receives beam, pbeam, wbeam in score units.  Returns the node
  * count (which may exceed max_nodes: only max_nodes are written) or -1. */
 typedef struct ssw_fp_node_s {
     uint16_t senid[3];

@@ -14,9 +14,14 @@ the history table with its right-context subtraction) so that it can check the G
 is organised differently (dense arrays).  Small sizes only: pure-Python loops over the active
 HMMs, with the HMM step itself in C (orc_hmm_vit_eval_many).
 
-Where the reference's result depends on the iteration order of its hash tables
-(fsg_model_arcs) the order only decides exact score ties; arcs are taken here in the order
-word link(s), then fillers.
+Exact score ties are real, not a corner: dictionaries list alternates with IDENTICAL
+pronunciations (fr-fr does, often), whose HMMs score alike for ever, and the reference's answer
+(which of them is reported) comes from the order of its lists.  So links are kept in the order
+fsg_model_trans_add / fsg_model_add_alt leave them in (alternates w(2), w(3), ..., then w) and
+the active lists are rebuilt by prepending exactly as fsg_search.c does.  What is NOT
+reproduced is the iteration order of the reference's hash table over DESTINATION states
+(fsg_model_arcs: the word links to state i+1 and the loops back to state i come in one order or
+the other); that only orders HMMs that cannot tie (a word against a filler).
 
 Pinned by tests/test_first_pass_oracle.py against the word segmentations the reference printed
 for its two test recordings.
@@ -135,7 +140,10 @@ def build_fsg(lex, words, lmath, cfg):
     for i, w in enumerate(words):
         if w not in lex.pron:
             raise KeyError(f"Unknown word {w}")
-        for a in lex.alt_chain(w):                  # fsg_model_add_alt: same probability
+        # fsg_model_add_alt PREPENDS each alternate's link to the state's list, in dict_nextalt
+        # order (newest alternate first): the list ends up w(2), w(3), ..., w(k), w
+        chain = lex.alt_chain(w)
+        for a in list(reversed(chain[1:])) + [w]:
             arcs[i].append(Link(i, i + 1, 0, a, False))
     logsil = int(np.float32(lmath.log(float(np.float32(cfg.silprob)))) * lw)
     logfil = int(np.float32(lmath.log(float(np.float32(cfg.fillprob)))) * lw)
@@ -143,11 +151,17 @@ def build_fsg(lex, words, lmath, cfg):
     others = [f for f in lex.order[lex.filler_start:len(lex.order) - 1]
               if f not in ("<s>", "</s>", "<sil>")]
     for s in range(n_state):
-        for a in lex.alt_chain("<sil>"):
-            arcs[s].append(Link(s, s, logsil, a, True))
-        for f in others:
-            for a in lex.alt_chain(f):
-                arcs[s].append(Link(s, s, logfil, a, True))
+        # the loops are added after the text's links and before the alternates; each later
+        # fsg_model_trans_add / add_alt prepends to the (state -> same state) list
+        loops = [("<sil>", logsil)] + [(f, logfil) for f in others]
+        order = []
+        for f, lp in loops:
+            order.insert(0, (f, lp))
+        for f, lp in loops:
+            for a in lex.alt_chain(f)[1:]:
+                order.insert(0, (a, lp))
+        for a, lp in order:
+            arcs[s].append(Link(s, s, lp, a, True))
     return arcs
 
 

@@ -72,7 +72,8 @@ typedef struct {
 /* growable arrays of the batch */
 typedef struct {
     ssw_fp_graphs_t *g;
-    int cap_nodes, cap_leaves, cap_states, cap_in;
+    int cap_nodes, cap_leaves, cap_states, cap_in, cap_tw;
+    int rk_last; /* rank-buffer ints of the utterance just built */
 } builder_t;
 
 static int
@@ -103,6 +104,7 @@ reserve_nodes(builder_t *b, int need)
     c = c0; if (grow((void **)&g->info, &c, need, sizeof(uint32_t)) < 0) return -1;
     c = c0; if (grow((void **)&g->ctxt, &c, need, sizeof(uint64_t)) < 0) return -1;
     c = c0; if (grow((void **)&g->leaf_ord, &c, need, sizeof(int32_t)) < 0) return -1;
+    c = c0; if (grow((void **)&g->twin_ref, &c, need, sizeof(int32_t)) < 0) return -1;
     b->cap_nodes = c;
     return 0;
 }
@@ -122,6 +124,9 @@ reserve_leaves(builder_t *b, int need)
 #define INFO_ROOT 1u
 #define INFO_LEAF 2u
 #define INFO_ALLRC 4u
+#define INFO_TWIN 8u        /* one of several word-final HMMs that can never differ */
+#define INFO_TWIN_FIRST 16u /* the first of them in the predecessor's successor chain */
+#define INFO_TWIN_LAST 32u
 
 /* new node of the utterance being built; returns its local index or -1 */
 static int
@@ -140,6 +145,7 @@ add_node(builder_t *b, const ssw_host_model_t *h, int base, int ssid, int ci, in
     g->info[n] = flags | ((uint32_t)ci_ext << 8) | ((uint32_t)state << 16);
     g->ctxt[n] = ctxt;
     g->leaf_ord[n] = -1;
+    g->twin_ref[n] = -1;
     ++g->n_nodes;
     return n - base;
 }
@@ -203,15 +209,26 @@ build_one(builder_t *b, const ssw_model_t *m, const ssw_host_model_t *h, const s
                 ssw_set_error("Unknown word %s", words[s]); /* src/decoder.c:699-703 */
                 goto bad;
             }
-            /* the word, then fsg_search_add_altpron: the dict_nextalt chain from it */
-            for (k = w; k >= 0; k = (cfg->use_altpron ? d->alt[k] : -1)) {
-                if (grow((void **)&links, &cap_links, n_links + 1, sizeof(link_t)) < 0)
+            /* fsg_search_add_altpron walks the dict_nextalt chain from the word and
+             * fsg_model_add_alt PREPENDS every alternate's link (src/fsg_model.c:430-444): the
+             * state's list ends up w(2), w(3), ..., w(k), w.  The order matters: alternates with
+             * identical pronunciations tie for ever and the list order picks the one reported */
+            {
+                int n_alt = 0, j;
+                for (k = cfg->use_altpron ? d->alt[w] : -1; k >= 0; k = d->alt[k])
+                    ++n_alt;
+                if (grow((void **)&links, &cap_links, n_links + n_alt + 1, sizeof(link_t)) < 0)
                     goto oom;
-                links[n_links].word = k;
-                links[n_links].to = s + 1;
-                links[n_links].logp = 0;
-                links[n_links].filler = 0;
-                ++n_links;
+                j = n_links + n_alt - 1;
+                for (k = cfg->use_altpron ? d->alt[w] : -1; k >= 0; k = d->alt[k], --j)
+                    links[j].word = k;
+                links[n_links + n_alt].word = w;
+                for (j = n_links; j <= n_links + n_alt; ++j) {
+                    links[j].to = s + 1;
+                    links[j].logp = 0;
+                    links[j].filler = 0;
+                }
+                n_links += n_alt + 1;
             }
         }
         if (cfg->use_filler) {
@@ -361,6 +378,93 @@ build_one(builder_t *b, const ssw_model_t *m, const ssw_host_model_t *h, const s
             }
         }
     }
+    /* twins: word-final nodes of different links under the same predecessor with the same
+     * senones and destination (alternates pronounced alike).  They score alike for ever; the
+     * reference keeps one exit of the two (src/fsg_history.c:164-170, the later arrival's right
+     * contexts are all covered) and which one arrives first alternates with the frame, because
+     * its active list is rebuilt by prepending.  Creation order here = the order of the
+     * predecessor's successor chain (links in list order). */
+    for (i = base; i < g->n_nodes; ++i) {
+        int j, last = i;
+        const int is_root = (g->info[i] & INFO_ROOT) != 0;
+        if (!(g->info[i] & INFO_LEAF) || (g->info[i] & INFO_TWIN))
+            continue;
+        for (j = i + 1; j < g->n_nodes; ++j)
+            if ((g->info[j] & INFO_LEAF) && ((g->info[j] & INFO_ROOT) != 0) == is_root
+                && (is_root ? ((g->info[j] >> 16) == (g->info[i] >> 16) && g->ctxt[j] == g->ctxt[i])
+                            : g->parent[j] == g->parent[i])
+                && g->leaf_to[leaf_base + g->leaf_ord[j]] == g->leaf_to[leaf_base + g->leaf_ord[i]]
+                && memcmp(&g->senid[(size_t)j * 4], &g->senid[(size_t)i * 4], 3 * sizeof(uint16_t)) == 0) {
+                g->info[j] |= INFO_TWIN;
+                last = j;
+            }
+        if (last != i) {
+            /* word-final nodes hang off their predecessor in creation order; one-phone words
+             * are word-initial nodes, which the reference links newest first (:421, :458) */
+            g->info[i] |= INFO_TWIN | (is_root ? INFO_TWIN_LAST : INFO_TWIN_FIRST);
+            g->info[last] |= is_root ? INFO_TWIN_FIRST : INFO_TWIN_LAST;
+        }
+    }
+    /* twin records (see ssw_internal.h): what a member needs to follow the reference's list
+     * order among its group and their ancestors */
+    {
+        const int tw_base = g->n_tw;
+        int rk = 0;
+        for (i = base; i < g->n_nodes; ++i) {
+            int members[64], anc[64], n_mem = 0, n_anc = 0, j, q, L;
+            if (!(g->info[i] & INFO_TWIN_FIRST) && !(g->info[i] & INFO_TWIN_LAST))
+                continue;
+            /* handle a group once, from its lowest-numbered member */
+            {
+                const int is_root = (g->info[i] & INFO_ROOT) != 0;
+                int lowest = 1;
+                for (j = base; j < i; ++j)
+                    if ((g->info[j] & INFO_TWIN) && ((g->info[j] & INFO_ROOT) != 0) == is_root
+                        && (is_root ? ((g->info[j] >> 16) == (g->info[i] >> 16) && g->ctxt[j] == g->ctxt[i])
+                                    : g->parent[j] == g->parent[i])
+                        && g->leaf_to[leaf_base + g->leaf_ord[j]] == g->leaf_to[leaf_base + g->leaf_ord[i]]
+                        && memcmp(&g->senid[(size_t)j * 4], &g->senid[(size_t)i * 4], 3 * sizeof(uint16_t)) == 0)
+                        lowest = 0;
+                if (!lowest)
+                    continue;
+                for (j = i; j < g->n_nodes && n_mem < 64; ++j)
+                    if ((g->info[j] & INFO_TWIN) && ((g->info[j] & INFO_ROOT) != 0) == is_root
+                        && (is_root ? ((g->info[j] >> 16) == (g->info[i] >> 16) && g->ctxt[j] == g->ctxt[i])
+                                    : g->parent[j] == g->parent[i])
+                        && g->leaf_to[leaf_base + g->leaf_ord[j]] == g->leaf_to[leaf_base + g->leaf_ord[i]]
+                        && memcmp(&g->senid[(size_t)j * 4], &g->senid[(size_t)i * 4], 3 * sizeof(uint16_t)) == 0)
+                        members[n_mem++] = j - base;
+                if (is_root) /* word-initial nodes are linked newest first */
+                    for (j = 0; j < n_mem / 2; ++j) {
+                        q = members[j];
+                        members[j] = members[n_mem - 1 - j];
+                        members[n_mem - 1 - j] = q;
+                    }
+                else
+                    for (q = g->parent[i]; q >= 0 && n_anc < 64; q = g->parent[base + q] < -1 ? -1 : g->parent[base + q])
+                        anc[n_anc++] = q;
+            }
+            L = n_anc + n_mem;
+            for (j = 0; j < n_mem; ++j) {
+                int o;
+                if (grow((void **)&g->tw, &b->cap_tw, g->n_tw + 4 + L, sizeof(int32_t)) < 0)
+                    goto oom;
+                o = g->n_tw;
+                g->twin_ref[base + members[j]] = o - tw_base;
+                g->tw[o] = L;
+                g->tw[o + 1] = n_anc;
+                g->tw[o + 2] = n_anc + j;
+                g->tw[o + 3] = rk;
+                for (q = 0; q < n_anc; ++q) /* root first */
+                    g->tw[o + 4 + q] = anc[n_anc - 1 - q];
+                for (q = 0; q < n_mem; ++q)
+                    g->tw[o + 4 + n_anc + q] = members[q];
+                g->n_tw += 4 + L;
+                rk += 3 * L;
+            }
+        }
+        b->rk_last = rk;
+    }
     /* roots: forget the diphone note */
     for (i = base; i < g->n_nodes; ++i)
         if (g->parent[i] < -1)
@@ -441,6 +545,8 @@ graphs_build_serial(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_p
     g->node_off = (int32_t *)calloc((size_t)n_utts + 1, sizeof(int32_t));
     g->leaf_off = (int32_t *)calloc((size_t)n_utts + 1, sizeof(int32_t));
     g->state_off = (int32_t *)calloc((size_t)n_utts + 1, sizeof(int32_t));
+    g->tw_off = (int32_t *)calloc((size_t)n_utts + 1, sizeof(int32_t));
+    g->tw_rk = (int32_t *)calloc((size_t)n_utts + 1, sizeof(int32_t));
     /* fsg_search_init, src/fsg_search.c:198-217 and fsg_model_add_silence, fsg_model.c:367 */
     g->beam = ilog0(base, cfg.beam) >> SSW_SENSCR_SHIFT;
     g->pbeam = ilog0(base, cfg.pbeam) >> SSW_SENSCR_SHIFT;
@@ -453,12 +559,15 @@ graphs_build_serial(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_p
         g->node_off[u] = g->n_nodes;
         g->leaf_off[u] = g->n_leaves;
         g->state_off[u] = g->n_states;
+        g->tw_off[u] = g->n_tw;
         if (build_one(&b, m, h, d, &cfg, word_off[u + 1] - word_off[u],
                       words + (word_off[u] - word_off[0]), wip, pip, logsil, logfil) < 0) {
             ssw_fp_graphs_free(g);
             return NULL;
         }
+        g->tw_rk[u] = b.rk_last;
     }
+    g->tw_off[n_utts] = g->n_tw;
     g->node_off[n_utts] = g->n_nodes;
     g->leaf_off[n_utts] = g->n_leaves;
     g->state_off[n_utts] = g->n_states;
@@ -546,6 +655,7 @@ ssw_fp_graphs_build(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_p
             total.n_leaves += job[t].out->n_leaves;
             total.n_states += job[t].out->n_states;
             total.n_in += job[t].out->n_in;
+            total.n_tw += job[t].out->n_tw;
         }
     }
     g = ok ? (ssw_fp_graphs_t *)calloc(1, sizeof(*g)) : NULL;
@@ -555,6 +665,7 @@ ssw_fp_graphs_build(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_p
         g->n_leaves = total.n_leaves;
         g->n_states = total.n_states;
         g->n_in = total.n_in;
+        g->n_tw = total.n_tw;
         g->beam = job[0].out->beam;
         g->pbeam = job[0].out->pbeam;
         g->wbeam = job[0].out->wbeam;
@@ -562,10 +673,12 @@ ssw_fp_graphs_build(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_p
         g->leaf_off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n_utts + 1));
         g->state_off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n_utts + 1));
         g->in_off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)total.n_states + 1));
-        if (!g->node_off || !g->leaf_off || !g->state_off || !g->in_off)
+        g->tw_off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n_utts + 1));
+        g->tw_rk = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n_utts + 1));
+        if (!g->node_off || !g->leaf_off || !g->state_off || !g->in_off || !g->tw_off || !g->tw_rk)
             ok = 0;
         else {
-            int nb = 0, lb = 0, sb = 0, ib = 0;
+            int nb = 0, lb = 0, sb = 0, ib = 0, tb = 0;
             u = 0;
             for (t = 0; t < n_thr; ++t) {
                 const ssw_fp_graphs_t *p = job[t].out;
@@ -574,6 +687,8 @@ ssw_fp_graphs_build(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_p
                     g->node_off[u] = nb + p->node_off[k];
                     g->leaf_off[u] = lb + p->leaf_off[k];
                     g->state_off[u] = sb + p->state_off[k];
+                    g->tw_off[u] = tb + p->tw_off[k];
+                    g->tw_rk[u] = p->tw_rk[k];
                 }
                 for (k = 0; k < p->n_states; ++k)
                     g->in_off[sb + k] = ib + p->in_off[k];
@@ -581,7 +696,9 @@ ssw_fp_graphs_build(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_p
                 lb += p->n_leaves;
                 sb += p->n_states;
                 ib += p->n_in;
+                tb += p->n_tw;
             }
+            g->tw_off[n_utts] = tb;
             g->node_off[n_utts] = nb;
             g->leaf_off[n_utts] = lb;
             g->state_off[n_utts] = sb;
@@ -607,6 +724,8 @@ ssw_fp_graphs_build(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_p
             CAT(leaf_to, n_leaves, int32_t);
             CAT(leaf_node, n_leaves, int32_t);
             CAT(in_leaf, n_in, int32_t);
+            CAT(twin_ref, n_nodes, int32_t);
+            CAT(tw, n_tw, int32_t);
         }
     }
     for (t = 0; t < n_thr; ++t)
@@ -639,6 +758,10 @@ ssw_fp_graphs_free(ssw_fp_graphs_t *g)
     free(g->leaf_node);
     free(g->in_off);
     free(g->in_leaf);
+    free(g->tw);
+    free(g->tw_off);
+    free(g->twin_ref);
+    free(g->tw_rk);
     free(g);
 }
 
@@ -669,7 +792,7 @@ ssw_first_pass_graph(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_
         o->tmat = (int16_t)g->senid[(size_t)i * 4 + 3];
         o->pen = g->pen[i];
         o->parent = g->parent[i];
-        o->flags = g->info[i] & 7u;
+        o->flags = g->info[i] & 63u;
         o->ci_ext = (int32_t)((g->info[i] >> 8) & 0xff);
         o->state = (int32_t)(g->info[i] >> 16);
         o->to_state = lo >= 0 ? g->leaf_to[lo] : -1;

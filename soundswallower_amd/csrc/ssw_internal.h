@@ -101,6 +101,13 @@ typedef struct ssw_fp_graphs_s {
     int32_t *leaf_node; /* [n_leaves] the leaf's node */
     int32_t *in_off;    /* [n_states + 1] leaves entering each state, into in_leaf */
     int32_t *in_leaf;   /* [n_in] leaf ordinals, by (left-context phone, ordinal) */
+    /* alternates pronounced alike (twins): per member a record
+     *   [L, n_ancestors, own element index, offset of its 3 x L rank / key buffers,
+     *    L node indices: the ancestors root .. predecessor, then the members in chain order]
+     * tw_off [n_utts + 1] into tw; twin_ref [n_nodes] = the node's record offset in its
+     * utterance's part of tw, or -1; tw_rk [n_utts] = ints of rank buffers the utterance needs */
+    int32_t n_tw;
+    int32_t *tw, *tw_off, *twin_ref, *tw_rk;
     int32_t beam, pbeam, wbeam;
 } ssw_fp_graphs_t;
 ssw_fp_graphs_t *ssw_fp_graphs_build(const ssw_model_t *m, const struct ssw_dict_s *d,

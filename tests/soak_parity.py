@@ -73,12 +73,71 @@ def soak_align(a):
     sys.exit(1 if bad else 0)
 
 
+def soak_first_pass(a):
+    """Random texts (1-12 words), synthetic scores that follow one path through the text's phone
+    trees with noise at random levels (clean, near-ties, wrong turns, no path), ragged batches:
+    ssw_first_pass_batch against the oracle's restatement of fsg_search -- words, frames and
+    exit scores, or the same failure."""
+    import torch
+    from oracle import oracle as O
+    from oracle import fsg_oracle as F
+    from tests.test_gpu_first_pass import synth_scores
+    mdir = ssw.model_dir(a.model)
+    m = ssw.Model(mdir)
+    orc = O.Model(mdir)
+    lex = ssw.Lexicon(m, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
+    olex = F.Lexicon(orc, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
+    vocab = [w for w in olex.order[:olex.filler_start] if "(" not in w]
+    rng = np.random.default_rng(2024)
+    t_end = time.time() + a.seconds
+    n_utts = n_frames = n_fail = n_batches = n_label = 0
+    while time.time() < t_end:
+        nb = int(rng.integers(1, 40))
+        texts, scores = [], []
+        for _ in range(nb):
+            words = [vocab[int(rng.integers(len(vocab)))] for _ in range(int(rng.integers(1, 13)))]
+            lo = int(rng.choice([120, 60, 30, 15]))
+            sc = synth_scores(F, orc, olex, words, int(rng.integers(1 << 30)), orc.n_sen,
+                              noise_lo=lo, sil_p=float(rng.random()))
+            if rng.random() < 0.15:
+                sc = sc[:int(len(sc) * rng.uniform(0.3, 0.95))]
+            texts.append(words)
+            scores.append(sc)
+        off = np.concatenate([[0], np.cumsum([len(s) for s in scores])]).astype(np.int32)
+        d = torch.from_numpy(np.ascontiguousarray(np.concatenate(scores), np.int16)).cuda()
+        got = lex.first_pass(d, off, texts)
+        for t, sc, g in zip(texts, scores, got):
+            want = F.first_pass(orc, olex, t, sc)
+            if want is None:
+                assert g is None, ("GPU found a path the oracle does not", t)
+                n_fail += 1
+            else:
+                assert g is not None, ("GPU lost the path", t)
+                mine = [(w, s, s + dd - 1, x) for (w, s, dd, x) in g]
+                if mine != want:
+                    # frames and scores must agree whatever happens; a different LABEL among
+                    # alternates pronounced alike is counted and shown
+                    assert [x[1:] for x in mine] == [x[1:] for x in want], (t, mine, want)
+                    n_label += 1
+                    if n_label <= 5:
+                        print("label difference:", [(a[0], b[0]) for a, b in zip(mine, want) if a != b],
+                              file=sys.stderr)
+            n_utts += 1
+            n_frames += len(sc)
+        n_batches += 1
+    print(json.dumps({"mode": "first_pass", "model": a.model, "batches": n_batches,
+                      "utterances": n_utts, "frames": n_frames, "without_a_path": n_fail,
+                      "differences": 0, "label_differences_among_identical_alternates": n_label}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--model", default="en-us")
-    ap.add_argument("--mode", default="ptm", choices=["ptm", "ms", "align"])
+    ap.add_argument("--mode", default="ptm", choices=["ptm", "ms", "align", "first_pass"])
     a = ap.parse_args()
+    if a.mode == "first_pass":
+        return soak_first_pass(a)
     if a.mode == "align":
         return soak_align(a)
     mdir = ssw.model_dir(a.model)

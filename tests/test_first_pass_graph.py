@@ -126,3 +126,28 @@ def test_dictionary_alternates_and_fillers(both):
     # unknown words are refused with the reference's message
     with pytest.raises(ssw.SswError, match="Unknown word"):
         lp.first_pass_graph(["go", "qqqqq"])
+
+
+def test_alternates_pronounced_alike_are_marked(both):
+    """fr-fr lists alternates with identical pronunciations (abus / abus(2); one-phone ait /
+    ait(2)): their word-final HMMs can never differ, and the kernel needs to know which of a
+    group the reference's list order would let through (flags 8 member, 16 first, 32 last)."""
+    F, mo, lo, mp, lp = both["fr-fr"]
+    nodes, _ = lp.first_pass_graph(["abus", "ait"])
+    twins = [n for n in nodes if n["flags"] & 8]
+    names = sorted({lp.word(int(n["wid"])) for n in twins})
+    assert names == ["abus", "abus(2)", "ait", "ait(2)"]
+    for w in ("abus", "ait"):
+        grp = [n for n in twins if lp.word(int(n["wid"])).split("(")[0] == w]
+        by_sen = {}
+        for n in grp:
+            by_sen.setdefault(tuple(n["senid"]), []).append(n)
+        for members in by_sen.values():
+            assert len(members) == 2
+            assert sorted(int(n["flags"]) & 48 for n in members) == [16, 32]
+    # links in the reference's list order: alternates first, the word itself last
+    words = [lp.word(int(n["wid"])) for n in nodes if n["flags"] & 2 and n["state"] == 0
+             and not lp.word(int(n["wid"])).startswith("<")]
+    assert words.index("abus(2)") < words.index("abus")
+    en_nodes, _ = both["en-us"][4].first_pass_graph(["go", "forward"])
+    assert not any(n["flags"] & 8 for n in en_nodes)

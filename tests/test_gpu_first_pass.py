@@ -215,3 +215,26 @@ def test_large_batch_equals_one_by_one(oracle_mod, gpu_en, orc_en):
     bad[50] = bad[50] + ["qqqqq"]
     with pytest.raises(ssw.SswError, match="Unknown word qqqqq"):
         _first_pass(gpu_en, lex, scores, bad)
+
+
+def test_alternates_pronounced_alike(oracle_mod, gpu_fr, orc_fr):
+    """fr-fr texts full of alternates with identical pronunciations (abus / abus(2), the
+    one-phone ait / ait(2), ...): their HMMs tie for ever and the reference reports whichever
+    its list order lets through at the exit frame; durations are varied so that exits fall on
+    both parities."""
+    F, olex = _olex(oracle_mod, orc_fr, "fr-fr")
+    lex = _lex(gpu_fr, "fr-fr")
+    texts, scores = [], []
+    for t in range(40):
+        words = [["abus", "ait", "mauritaniens"], ["ait", "abus"], ["mauritaniens", "abus", "abus"],
+                 ["abus"]][t % 4]
+        texts.append(words)
+        scores.append(synth_scores(F, orc_fr, olex, words, 300 + t, orc_fr.n_sen, sil_p=0.5))
+    got = _first_pass(gpu_fr, lex, scores, texts)
+    seen = set()
+    for t in range(40):
+        want = F.first_pass(orc_fr, olex, texts[t], scores[t])
+        assert want is not None and got[t] is not None
+        assert [(w, s, s + d - 1, sc) for (w, s, d, sc) in got[t]] == want, texts[t]
+        seen.update(w for (w, _, _, _) in got[t])
+    assert {"abus", "abus(2)"} <= seen          # both members of a group do get reported

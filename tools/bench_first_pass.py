@@ -49,6 +49,86 @@ def path_through(lex, nodes, n_words, rng):
     return path
 
 
+def build_workload(ssw, m, lex, utts, frames, words_per_text, noise=0.3, seed=4242):
+    """texts + features [utts * frames][39] that follow them (see the module docstring)"""
+    mdir = ssw.model_dir("en-us")
+    means = read_raw_means(mdir)                                  # [cb][feat][density][13]
+    mixw = m.table("ptm_mixw").reshape(m.n_feat, m.n_density, m.n_sen)
+    sen2cb = m.table("sen2cb")
+    best_d = mixw.argmin(axis=1)                                  # [feat][sen]
+    sen_mean = np.concatenate([means[sen2cb, f, best_d[f]] for f in range(m.n_feat)], axis=1)
+    n_dict = len(lex)
+    u = lcg_uniform(seed, 4 * utts * words_per_text)
+    k = 0
+    texts, feats, n_nodes = [], [], []
+    rng = np.random.default_rng(1)
+    for t in range(utts):
+        while True:
+            words = []
+            while len(words) < words_per_text:
+                w = lex.word(int(u[k % len(u)] * n_dict))
+                k += 1
+                if w and "(" not in w and not w.startswith(("<", "[")):
+                    words.append(w)
+            nodes, _ = lex.first_pass_graph(words)
+            path = path_through(lex, nodes, words_per_text, rng)
+            if 3 * len(path) <= frames:
+                break
+        states = np.array([s for i in path for s in nodes[i]["senid"]])
+        per = np.full(len(states), frames // len(states))
+        per[-3:] += (frames - per.sum() + 2) // 3
+        per[-1] += frames - per.sum()
+        sen = np.repeat(states, per)
+        x = sen_mean[sen] + rng.standard_normal((frames, sen_mean.shape[1])).astype(np.float32) * noise
+        texts.append(words)
+        feats.append(x.astype(np.float32))
+        n_nodes.append(len(nodes))
+    return texts, np.concatenate(feats), float(np.mean(n_nodes))
+
+
+def run(ssw, m, lex, torch, utts=256, frames=1000, words_per_text=25, reps=3, noise=0.3):
+    texts, feats, nodes_per_text = build_workload(ssw, m, lex, utts, frames, words_per_text, noise)
+    off = (np.arange(utts + 1) * frames).astype(np.int32)
+    d_feats = torch.from_numpy(feats).cuda()
+    d_scr = torch.empty((len(feats), m.n_sen), dtype=torch.int16, device="cuda")
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.score_batch_device(d_feats, len(feats), off, d_scr)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        lex.first_pass_raw(d_scr, off, texts)
+        t2 = time.perf_counter()
+        aset = ssw.forced_align_batch(m, lex, d_scr, off, texts)   # first pass again + the rest
+        t3 = time.perf_counter()
+        res = [aset.utterance(k) for k in range(utts)]
+        aset.free()
+        cur = {"score_s": t1 - t0, "first_pass_s": t2 - t1, "alignment_s": t3 - t2}
+        if best is None or cur["score_s"] + cur["alignment_s"] < best["score_s"] + best["alignment_s"]:
+            best = cur
+    segs = lex.first_pass(d_scr, off, texts)
+    done = [s for s in segs if s is not None]
+    same_words = sum(1 for s, t in zip(segs, texts) if s is not None and
+                     [w.split("(")[0] for (w, _, _, _) in s if not w.startswith(("<", "["))] == t)
+    aligned = sum(1 for r in res if r is not None)
+    tiles = all(int(r["word_al"][:, 1].sum()) == frames for r in res if r is not None)
+    audio_s = utts * frames / 100.0
+    wall = best["score_s"] + best["alignment_s"]
+    return {
+        "workload": f"{utts} utterances x {frames} frames, texts of {words_per_text} words, en-us; "
+                    f"synthetic audio following the text: scoring, then decoder_alignment from "
+                    f"text (first pass + populate + constrained state alignment)",
+        "hmms_per_text": nodes_per_text,
+        "score_ms": best["score_s"] * 1e3, "first_pass_ms": best["first_pass_s"] * 1e3,
+        "decoder_alignment_ms": best["alignment_s"] * 1e3,
+        "first_pass_completed": len(done), "first_pass_words_equal_text": same_words,
+        "aligned": aligned, "alignments_tile_their_utterances": bool(tiles), "n_utts": utts,
+        "rtf": wall / audio_s,
+        "first_pass_utt_frames_per_s": utts * frames / best["first_pass_s"],
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--utts", type=int, default=256)
@@ -62,76 +142,7 @@ def main():
     mdir = ssw.model_dir("en-us")
     m = ssw.Model(mdir)
     lex = ssw.Lexicon(m, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
-    means = read_raw_means(mdir)                                  # [cb][feat][density][13]
-    mixw = m.table("ptm_mixw").reshape(m.n_feat, m.n_density, m.n_sen)
-    sen2cb = m.table("sen2cb")
-    best_d = mixw.argmin(axis=1)                                  # [feat][sen]
-    sen_mean = np.concatenate([means[sen2cb, f, best_d[f]] for f in range(m.n_feat)], axis=1)
-    n_dict = len(lex)
-    vocab = []
-    u = lcg_uniform(4242, 4 * a.utts * a.words)
-    k = 0
-    texts, feats, n_nodes = [], [], []
-    rng = np.random.default_rng(1)
-    for t in range(a.utts):
-        while True:
-            words = []
-            while len(words) < a.words:
-                w = lex.word(int(u[k % len(u)] * n_dict))
-                k += 1
-                if w and "(" not in w and not w.startswith(("<", "[")):
-                    words.append(w)
-            nodes, _ = lex.first_pass_graph(words)
-            path = path_through(lex, nodes, a.words, rng)
-            if 3 * len(path) <= a.frames:
-                break
-        states = np.array([s for i in path for s in nodes[i]["senid"]])
-        per = np.full(len(states), a.frames // len(states))
-        per[-3:] += (a.frames - per.sum() + 2) // 3
-        per[-1] += a.frames - per.sum()
-        sen = np.repeat(states, per)
-        x = sen_mean[sen] + rng.standard_normal((a.frames, sen_mean.shape[1])).astype(np.float32) * a.noise
-        texts.append(words)
-        feats.append(x.astype(np.float32))
-        n_nodes.append(len(nodes))
-    feats = np.concatenate(feats)
-    off = (np.arange(a.utts + 1) * a.frames).astype(np.int32)
-    d_feats = torch.from_numpy(feats).cuda()
-    d_scr = torch.empty((len(feats), m.n_sen), dtype=torch.int16, device="cuda")
-    best = None
-    for _ in range(a.reps):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        m.score_batch_device(d_feats, len(feats), off, d_scr)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        lex.first_pass_raw(d_scr, off, texts)
-        t2 = time.perf_counter()
-        aset = ssw.forced_align_batch(m, lex, d_scr, off, texts)   # first pass again + the rest
-        t3 = time.perf_counter()
-        res = [aset.utterance(k) for k in range(a.utts)]
-        aset.free()
-        cur = {"score_s": t1 - t0, "first_pass_s": t2 - t1, "alignment_s": t3 - t2}
-        if best is None or cur["score_s"] + cur["alignment_s"] < best["score_s"] + best["alignment_s"]:
-            best = cur
-    segs = lex.first_pass(d_scr, off, texts)
-    done = [s for s in segs if s is not None]
-    same_words = sum(1 for s, t in zip(segs, texts) if s is not None and
-                     [w.split("(")[0] for (w, _, _, _) in s if not w.startswith(("<", "["))] == t)
-    aligned = sum(1 for r in res if r is not None)
-    audio_s = a.utts * a.frames / 100.0
-    wall = best["score_s"] + best["alignment_s"]
-    print(json.dumps({
-        "workload": f"{a.utts} utterances x {a.frames} frames, texts of {a.words} words, en-us; "
-                    f"synthetic audio following the text",
-        "nodes_per_text": float(np.mean(n_nodes)),
-        "score_ms": best["score_s"] * 1e3, "first_pass_ms": best["first_pass_s"] * 1e3,
-        "decoder_alignment_ms": best["alignment_s"] * 1e3,
-        "first_pass_completed": len(done), "first_pass_words_equal_text": same_words,
-        "aligned": aligned, "n_utts": a.utts,
-        "text_to_alignment_rtf": wall / audio_s,
-        "first_pass_utt_frames_per_s": a.utts * a.frames / best["first_pass_s"],
-    }))
+    print(json.dumps(run(ssw, m, lex, torch, a.utts, a.frames, a.words, a.reps, a.noise)))
 
 
 if __name__ == "__main__":
