@@ -184,6 +184,22 @@ same_ssid(const ssw_fp_graphs_t *g, const ssw_host_model_t *h, int node, int ssi
     return 1;
 }
 
+/* word-final nodes i and j (absolute indices) that can never differ: the same senones into the
+ * same destination, under the same predecessor -- or, for one-phone words, hanging off the same
+ * state with the same left contexts */
+static int
+alike(const ssw_fp_graphs_t *g, int leaf_base, int i, int j)
+{
+    const int is_root = (g->info[i] & INFO_ROOT) != 0;
+    if (!(g->info[j] & INFO_LEAF) || ((g->info[j] & INFO_ROOT) != 0) != is_root)
+        return 0;
+    if (is_root ? ((g->info[j] >> 16) != (g->info[i] >> 16) || g->ctxt[j] != g->ctxt[i])
+                : g->parent[j] != g->parent[i])
+        return 0;
+    return g->leaf_to[leaf_base + g->leaf_ord[j]] == g->leaf_to[leaf_base + g->leaf_ord[i]]
+        && memcmp(&g->senid[(size_t)j * 4], &g->senid[(size_t)i * 4], 3 * sizeof(uint16_t)) == 0;
+}
+
 static int
 build_one(builder_t *b, const ssw_model_t *m, const ssw_host_model_t *h, const ssw_dict_t *d,
           const ssw_first_pass_config_t *cfg, int n_words, const char *const *words, int wip,
@@ -390,11 +406,7 @@ build_one(builder_t *b, const ssw_model_t *m, const ssw_host_model_t *h, const s
         if (!(g->info[i] & INFO_LEAF) || (g->info[i] & INFO_TWIN))
             continue;
         for (j = i + 1; j < g->n_nodes; ++j)
-            if ((g->info[j] & INFO_LEAF) && ((g->info[j] & INFO_ROOT) != 0) == is_root
-                && (is_root ? ((g->info[j] >> 16) == (g->info[i] >> 16) && g->ctxt[j] == g->ctxt[i])
-                            : g->parent[j] == g->parent[i])
-                && g->leaf_to[leaf_base + g->leaf_ord[j]] == g->leaf_to[leaf_base + g->leaf_ord[i]]
-                && memcmp(&g->senid[(size_t)j * 4], &g->senid[(size_t)i * 4], 3 * sizeof(uint16_t)) == 0) {
+            if (alike(g, leaf_base, i, j)) {
                 g->info[j] |= INFO_TWIN;
                 last = j;
             }
@@ -419,20 +431,12 @@ build_one(builder_t *b, const ssw_model_t *m, const ssw_host_model_t *h, const s
                 const int is_root = (g->info[i] & INFO_ROOT) != 0;
                 int lowest = 1;
                 for (j = base; j < i; ++j)
-                    if ((g->info[j] & INFO_TWIN) && ((g->info[j] & INFO_ROOT) != 0) == is_root
-                        && (is_root ? ((g->info[j] >> 16) == (g->info[i] >> 16) && g->ctxt[j] == g->ctxt[i])
-                                    : g->parent[j] == g->parent[i])
-                        && g->leaf_to[leaf_base + g->leaf_ord[j]] == g->leaf_to[leaf_base + g->leaf_ord[i]]
-                        && memcmp(&g->senid[(size_t)j * 4], &g->senid[(size_t)i * 4], 3 * sizeof(uint16_t)) == 0)
+                    if ((g->info[j] & INFO_TWIN) && alike(g, leaf_base, i, j))
                         lowest = 0;
                 if (!lowest)
                     continue;
                 for (j = i; j < g->n_nodes && n_mem < 64; ++j)
-                    if ((g->info[j] & INFO_TWIN) && ((g->info[j] & INFO_ROOT) != 0) == is_root
-                        && (is_root ? ((g->info[j] >> 16) == (g->info[i] >> 16) && g->ctxt[j] == g->ctxt[i])
-                                    : g->parent[j] == g->parent[i])
-                        && g->leaf_to[leaf_base + g->leaf_ord[j]] == g->leaf_to[leaf_base + g->leaf_ord[i]]
-                        && memcmp(&g->senid[(size_t)j * 4], &g->senid[(size_t)i * 4], 3 * sizeof(uint16_t)) == 0)
+                    if ((g->info[j] & INFO_TWIN) && alike(g, leaf_base, i, j))
                         members[n_mem++] = j - base;
                 if (is_root) /* word-initial nodes are linked newest first */
                     for (j = 0; j < n_mem / 2; ++j) {
@@ -609,7 +613,9 @@ build_thread(void *arg)
         else {                                                                               \
             size_t at = 0;                                                                   \
             for (t = 0; t < n_thr; ++t) {                                                    \
-                memcpy(g->field + at, job[t].out->field, sizeof(type) * (size_t)job[t].out->count_field); \
+                if (job[t].out->count_field)                                                 \
+                    memcpy(g->field + at, job[t].out->field,                                 \
+                           sizeof(type) * (size_t)job[t].out->count_field);                  \
                 at += (size_t)job[t].out->count_field;                                       \
             }                                                                                \
         }                                                                                    \
