@@ -178,8 +178,8 @@ def test_text_and_audio_to_the_reference_json(oracle_mod, gpu_en):
 
 
 def test_long_texts_use_the_wider_kernels(oracle_mod, gpu_en, orc_en):
-    """Texts of 60 and 150 words: more than 512 / 1024 phone-tree HMMs, i.e. 4 and 8 nodes per
-    thread; same results as the oracle."""
+    """Texts of 60 and 150 words: more than 512 / 1024 phone-tree HMMs, i.e. the 1024-thread
+    instances with one and two HMMs per thread; same results as the oracle."""
     F, olex = _olex(oracle_mod, orc_en, "en-us")
     lex = _lex(gpu_en, "en-us")
     vocab = [w for w in olex.order[:olex.filler_start] if "(" not in w]
