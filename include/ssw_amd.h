@@ -225,6 +225,10 @@ int32_t ssw_alignment_populate(const ssw_model_t *m, const ssw_dict_t *d, int32_
  * "forward(2)".  ssw_dict_word returns NULL and ssw_dict_word_id -1 when unknown. */
 const char *ssw_dict_word(const ssw_dict_t *d, int32_t wid);
 int32_t ssw_dict_word_id(const ssw_dict_t *d, const char *word);
+/* dict_basewid (the word an alternate belongs to; itself otherwise) and dict_filler_word
+ * (from the filler dictionary, <s> and </s> excepted; src/dict.c:373-384) */
+int32_t ssw_dict_base_id(const ssw_dict_t *d, int32_t wid);
+int32_t ssw_dict_is_filler(const ssw_dict_t *d, int32_t wid);
 
 /* ------------------------------------------------------------------------------------ */
 /* First pass of forced alignment: which fillers and alternate          */
@@ -293,6 +297,14 @@ int32_t ssw_alignment_set_phones(const ssw_alignment_set_t *a, int32_t utt, cons
                                  const int32_t **parent, const ssw_align_entry_t **al);
 int32_t ssw_alignment_set_states(const ssw_alignment_set_t *a, int32_t utt,
                                  const uint16_t **senid, const ssw_align_entry_t **al);
+/* decoder_result_json(d, utt_start, align_level) for utterance `utt` of the set (align_level 1:
+ * words and phones, 2: states too): "t" of the top level is the hypothesis string as
+ * decoder_hyp builds it (base words, fillers left out), "d" the reference's decoder_n_frames
+ * (the utterance's frames + 1) / frate, word texts are dictionary strings ("de(2)").  The
+ * posterior of the first pass is not computed: top-level "p" is 1.000.  snprintf-style return;
+ * -1 when the utterance has no alignment. */
+int32_t ssw_alignment_set_json(const ssw_alignment_set_t *a, int32_t utt, double utt_start,
+                               int32_t frate, int32_t align_level, char *out, int32_t out_len);
 void ssw_alignment_set_free(ssw_alignment_set_t *a);
 
 /* The graph ssw_first_pass_batch searches for one text, node by node (host only, works without

@@ -133,6 +133,12 @@ def lib() -> C.CDLL:
         fn.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
     L.ssw_alignment_set_phones.restype = i32
     L.ssw_alignment_set_phones.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.ssw_alignment_set_json.restype = i32
+    L.ssw_alignment_set_json.argtypes = [vp, i32, C.c_double, i32, i32, C.c_char_p, i32]
+    L.ssw_dict_base_id.restype = i32
+    L.ssw_dict_base_id.argtypes = [vp, i32]
+    L.ssw_dict_is_filler.restype = i32
+    L.ssw_dict_is_filler.argtypes = [vp, i32]
     L.ssw_alignment_set_free.argtypes = [vp]
     L.ssw_alignment_set_free.restype = None
     L.ssw_ciphone_name.restype = C.c_char_p

@@ -513,6 +513,16 @@ class AlignmentSet:
                 "cipid": cipid, "parent": parent, "phone_al": phone_al,
                 "senid": senid.reshape(-1, 3), "state_al": state_al}
 
+    def json(self, u, align_level=1, utt_start=0.0, frate=100):
+        """ssw_alignment_set_json: the reference's one-line JSON for utterance u."""
+        need = self._L.ssw_alignment_set_json(self._a, u, float(utt_start), frate, align_level,
+                                              None, 0)
+        _check(need, "ssw_alignment_set_json")
+        buf = C.create_string_buffer(need + 1)
+        _check(self._L.ssw_alignment_set_json(self._a, u, float(utt_start), frate, align_level,
+                                              buf, need + 1), "ssw_alignment_set_json")
+        return buf.value.decode()
+
     def free(self):
         if self._a:
             self._L.ssw_alignment_set_free(self._a)

@@ -247,6 +247,24 @@ ssw_dict_word_id(const ssw_dict_t *d, const char *word)
 }
 
 int32_t
+ssw_dict_base_id(const ssw_dict_t *d, int32_t wid)
+{
+    return (wid >= 0 && wid < d->n_words) ? d->base[wid] : -1;
+}
+
+int32_t
+ssw_dict_is_filler(const ssw_dict_t *d, int32_t wid)
+{
+    int b;
+    if (wid < 0 || wid >= d->n_words)
+        return 0;
+    b = d->base[wid];
+    if (strcmp(d->word[b], "<s>") == 0 || strcmp(d->word[b], "</s>") == 0)
+        return 0;
+    return b >= d->filler_start;
+}
+
+int32_t
 ssw_dict_pron(const ssw_dict_t *d, const char *word, int32_t *ciphones, int32_t max)
 {
     int w = dict_find(d, word), i;

@@ -174,6 +174,13 @@ def test_text_and_audio_to_the_reference_json(oracle_mod, gpu_en):
     line = lex.alignment_json("go forward ten meters", a["words"], a["word_al"], a["cipid"],
                               a["parent"], a["phone_al"], n_frames=279)
     assert line.startswith(REF_JSON_PREFIX)
+    # ... and straight from the C result object, hypothesis string and duration included
+    aset = ssw.forced_align_batch(gpu_en, lex, d_scr, off, texts)
+    assert aset.status(0) == 0 and aset.status(1) == 1
+    assert aset.json(0) == line and aset.json(0, align_level=2).count('"t":"') > 3 * 18
+    with pytest.raises(ssw.SswError, match="no alignment"):
+        aset.json(1)
+    aset.free()
     lex.free()
 
 
