@@ -105,6 +105,8 @@ class Config:
     pip = 1.0
     silprob = 0.005
     fillprob = 1e-8
+    fsgusefiller = True
+    fsgusealtpron = True
 
 
 class Node:
@@ -142,7 +144,7 @@ def build_fsg(lex, words, lmath, cfg):
             raise KeyError(f"Unknown word {w}")
         # fsg_model_add_alt PREPENDS each alternate's link to the state's list, in dict_nextalt
         # order (newest alternate first): the list ends up w(2), w(3), ..., w(k), w
-        chain = lex.alt_chain(w)
+        chain = lex.alt_chain(w) if cfg.fsgusealtpron else [w]
         for a in list(reversed(chain[1:])) + [w]:
             arcs[i].append(Link(i, i + 1, 0, a, False))
     logsil = int(np.float32(lmath.log(float(np.float32(cfg.silprob)))) * lw)
@@ -150,7 +152,7 @@ def build_fsg(lex, words, lmath, cfg):
     # src/fsg_search.c:107-116: `wid < dict_filler_end` leaves the LAST filler word out
     others = [f for f in lex.order[lex.filler_start:len(lex.order) - 1]
               if f not in ("<s>", "</s>", "<sil>")]
-    for s in range(n_state):
+    for s in range(n_state if cfg.fsgusefiller else 0):
         # the loops are added after the text's links and before the alternates; each later
         # fsg_model_trans_add / add_alt prepends to the (state -> same state) list
         loops = [("<sil>", logsil)] + [(f, logfil) for f in others]
@@ -158,7 +160,7 @@ def build_fsg(lex, words, lmath, cfg):
         for f, lp in loops:
             order.insert(0, (f, lp))
         for f, lp in loops:
-            for a in lex.alt_chain(f)[1:]:
+            for a in (lex.alt_chain(f)[1:] if cfg.fsgusealtpron else []):
                 order.insert(0, (a, lp))
         for a, lp in order:
             arcs[s].append(Link(s, s, lp, a, True))

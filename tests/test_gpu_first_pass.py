@@ -48,14 +48,16 @@ def test_reference_recordings(oracle_mod, gpu_en, gpu_fr, orc_en, orc_fr, name, 
     assert [(w, s, s + d - 1, sc) for (w, s, d, sc) in seg] == want
 
 
-def synth_scores(F, orc, olex, words, seed, n_sen, noise_lo=120, noise_hi=400, sil_p=0.5):
+def synth_scores(F, orc, olex, words, seed, n_sen, noise_lo=120, noise_hi=400, sil_p=0.5,
+                 cfg=None):
     """Senone scores that follow one path through the text's phone trees: per state a few frames
     where that state's senone scores near 0 and everything else is `noise`; optional silences
     between words; alternates picked at random."""
     lmath = O = None
     from oracle import oracle as O
     lmath = O.Logmath(1.0001, 0)
-    arcs = F.build_fsg(olex, words, lmath, F.Config)
+    cfg = cfg or F.Config
+    arcs = F.build_fsg(olex, words, lmath, cfg)
     nodes, roots = F.build_lextree(orc, olex, arcs, 0, 0)
     rng = np.random.default_rng(seed)
     path = []
@@ -66,7 +68,7 @@ def synth_scores(F, orc, olex, words, seed, n_sen, noise_lo=120, noise_hi=400, s
                 return r
             r = r.sibling
     for s in range(len(arcs)):
-        if s == 0 or s == len(arcs) - 1 or rng.random() < sil_p:
+        if cfg.fsgusefiller and (s == 0 or s == len(arcs) - 1 or rng.random() < sil_p):
             path.append(sil_node(s))
         if s == len(arcs) - 1:
             break
@@ -245,3 +247,39 @@ def test_alternates_pronounced_alike(oracle_mod, gpu_fr, orc_fr):
         assert [(w, s, s + d - 1, sc) for (w, s, d, sc) in got[t]] == want, texts[t]
         seen.update(w for (w, _, _, _) in got[t])
     assert {"abus", "abus(2)"} <= seen          # both members of a group do get reported
+
+
+@pytest.mark.parametrize("kw", [
+    dict(beam=1e-20, pbeam=1e-20, wbeam=1e-10),
+    dict(use_filler=0),
+    dict(use_altpron=0),
+    dict(lw=9.5, wip=0.2, silprob=0.1, fillprob=1e-3),
+    dict(beam=1e-80, pbeam=1e-60, wbeam=1e-40, pip=0.5),
+])
+def test_search_parameters_reach_the_search(oracle_mod, gpu_fr, orc_fr, kw):
+    """beam / pbeam / wbeam, lw / wip / pip, silprob / fillprob, fsgusefiller, fsgusealtpron: the
+    same values on both sides, same outcome (fr-fr: alternates matter there)."""
+    F, olex = _olex(oracle_mod, orc_fr, "fr-fr")
+    lex = _lex(gpu_fr, "fr-fr")
+    names = {"use_filler": "fsgusefiller", "use_altpron": "fsgusealtpron"}
+    ocfg = type("Cfg", (F.Config,), {names.get(k, k): (bool(v) if k in names else v)
+                                     for k, v in kw.items()})
+    cfg = lex.first_pass_config(**kw)
+    vocab = [w for w in olex.order[:olex.filler_start] if "(" not in w]
+    u = lcg_uniform(123, 12 * 8)
+    texts = [[vocab[int(x * len(vocab))] for x in u[t * 8:t * 8 + 2 + t % 5]] for t in range(12)]
+    texts[0] = ["avance", "de", "dix", "mètres"]
+    scores = [synth_scores(F, orc_fr, olex, t, 40 + i, orc_fr.n_sen, noise_lo=60, cfg=ocfg)
+              for i, t in enumerate(texts)]
+    off = np.concatenate([[0], np.cumsum([len(s) for s in scores])]).astype(np.int32)
+    d = torch.from_numpy(np.ascontiguousarray(np.concatenate(scores), np.int16)).cuda()
+    got = lex.first_pass(d, off, texts, cfg=cfg)
+    n_ok = 0
+    for t, sc, g in zip(texts, scores, got):
+        want = F.first_pass(orc_fr, olex, t, sc, cfg=ocfg)
+        if want is None:
+            assert g is None, (kw, t)
+        else:
+            n_ok += 1
+            assert g is not None and [(w, s, s + dd - 1, x) for (w, s, dd, x) in g] == want, (kw, t)
+    assert n_ok >= 3
