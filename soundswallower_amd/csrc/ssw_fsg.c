@@ -405,7 +405,8 @@ build_one(builder_t *b, const ssw_model_t *m, const ssw_host_model_t *h, const s
         const int is_root = (g->info[i] & INFO_ROOT) != 0;
         if (!(g->info[i] & INFO_LEAF) || (g->info[i] & INFO_TWIN))
             continue;
-        for (j = i + 1; j < g->n_nodes; ++j)
+        /* a state's nodes are contiguous and twins hang off the same state */
+        for (j = i + 1; j < g->n_nodes && (g->info[j] >> 16) == (g->info[i] >> 16); ++j)
             if (alike(g, leaf_base, i, j)) {
                 g->info[j] |= INFO_TWIN;
                 last = j;
@@ -430,12 +431,12 @@ build_one(builder_t *b, const ssw_model_t *m, const ssw_host_model_t *h, const s
             {
                 const int is_root = (g->info[i] & INFO_ROOT) != 0;
                 int lowest = 1;
-                for (j = base; j < i; ++j)
+                for (j = i - 1; j >= base && (g->info[j] >> 16) == (g->info[i] >> 16); --j)
                     if ((g->info[j] & INFO_TWIN) && alike(g, leaf_base, i, j))
                         lowest = 0;
                 if (!lowest)
                     continue;
-                for (j = i; j < g->n_nodes && n_mem < 64; ++j)
+                for (j = i; j < g->n_nodes && n_mem < 64 && (g->info[j] >> 16) == (g->info[i] >> 16); ++j)
                     if ((g->info[j] & INFO_TWIN) && alike(g, leaf_base, i, j))
                         members[n_mem++] = j - base;
                 if (is_root) /* word-initial nodes are linked newest first */

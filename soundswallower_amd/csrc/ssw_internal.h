@@ -57,6 +57,9 @@ typedef struct ssw_host_model_s {
     uint8_t *ms_pdf;   /* [sen][feat][density] */
     /* log-add tables */
     uint8_t logadd8[256];
+    /* memo of bin_mdef_phone_id_nearest, [pos][base][left][right], -2 = not looked up yet
+     * (filled lazily by ssw_phone_id_nearest; racing writers store the same value) */
+    int32_t *pid_memo;
     int32_t logadd8_size;   /* entries produced by logmath_init (>= 256) */
     int32_t zero8;          /* logmath zero at shift 10 */
 } ssw_host_model_t;

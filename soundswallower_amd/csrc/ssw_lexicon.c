@@ -304,18 +304,54 @@ phone_id(const ssw_host_model_t *h, int ci, int lc, int rc, int wpos)
     return -1;
 }
 
-/* bin_mdef_phone_id_nearest */
+static int32_t phone_id_nearest_walk(const ssw_host_model_t *h, int32_t b, int32_t l, int32_t r,
+                                     int32_t pos);
+
+/* bin_mdef_phone_id_nearest, memoised per model: the graph builder and alignment_populate ask for
+ * the same few thousand triphones over and over */
 int32_t
 ssw_phone_id_nearest(const ssw_model_t *m, int32_t b, int32_t l, int32_t r, int32_t pos)
 {
-    const ssw_host_model_t *h = ssw_model_host(m);
-    int p, t;
+    ssw_host_model_t *h = (ssw_host_model_t *)ssw_model_host(m);
+    const size_t n = (size_t)h->n_ciphone;
+    int32_t *memo, p;
     if (b < 0 || b >= h->n_ciphone || l >= h->n_ciphone || r >= h->n_ciphone || pos < 0 || pos > 3) {
         ssw_set_error("phone ids out of range");
         return -1;
     }
     if (l < 0 || r < 0)
         return b;
+    memo = __atomic_load_n(&h->pid_memo, __ATOMIC_ACQUIRE);
+    if (memo == NULL) {
+        int32_t *fresh = (int32_t *)malloc(sizeof(int32_t) * 4 * n * n * n), *expect = NULL;
+        size_t i;
+        if (fresh == NULL)
+            return phone_id_nearest_walk(h, b, l, r, pos);
+        for (i = 0; i < 4 * n * n * n; ++i)
+            fresh[i] = -2;
+        if (__atomic_compare_exchange_n(&h->pid_memo, &expect, fresh, 0, __ATOMIC_ACQ_REL,
+                                        __ATOMIC_ACQUIRE))
+            memo = fresh;
+        else { /* another thread installed its table first */
+            free(fresh);
+            memo = expect;
+        }
+    }
+    {
+        int32_t *slot = &memo[(((size_t)pos * n + (size_t)b) * n + (size_t)l) * n + (size_t)r];
+        p = __atomic_load_n(slot, __ATOMIC_RELAXED);
+        if (p == -2) {
+            p = phone_id_nearest_walk(h, b, l, r, pos);
+            __atomic_store_n(slot, p, __ATOMIC_RELAXED);
+        }
+    }
+    return p;
+}
+
+static int32_t
+phone_id_nearest_walk(const ssw_host_model_t *h, int32_t b, int32_t l, int32_t r, int32_t pos)
+{
+    int p, t;
     if ((p = phone_id(h, b, l, r, pos)) >= 0)
         return p;
     for (t = 0; t < 4; ++t)

@@ -884,6 +884,7 @@ ssw_host_model_free(ssw_host_model_t *h)
     free(h->mean);
     free(h->var);
     free(h->det);
+    free(h->pid_memo);
     free(h->rec);
     free(h->recq);
     free(h->recd0);
