@@ -320,9 +320,11 @@ def _in(ctxt, ci):
     return (ctxt >> ci) & 1
 
 
-def first_pass(model, lex, words, senscr, cfg=Config, trace=None):
-    """Returns [(word, start_frame, end_frame)] as fsg_search_seg_iter yields them, or None when
-    the final state is not reached in the last frame that has word exits."""
+def first_pass(model, lex, words, senscr, cfg=Config, trace=None, n_frames=None):
+    """Returns [(word, start_frame, end_frame, exit score)] as fsg_search_seg_iter yields them,
+    or None when the final state is not reached in the last frame that has word exits.  senscr:
+    int16 [T][n_sen], or a function (frame, senone ids [n_active][3]) -> int16 [n_sen] row with
+    n_frames given (scoring interleaved with the search, as with compallsen=no)."""
     lmath = O.Logmath(1.0001, 0)
     lw = np.float32(cfg.lw)
     beam = int(lmath.log(cfg.beam)) >> SENSCR_SHIFT
@@ -404,13 +406,15 @@ def first_pass(model, lex, words, senscr, cfg=Config, trace=None):
     active = []
     entry_add(None, -1, 0, -1, model.sil, ALL_CTXT)
     word_trans(0, -1, 0, active)
-    T = len(senscr)
+    T = len(senscr) if not callable(senscr) else n_frames
     for f in range(T):
-        scr = np.ascontiguousarray(senscr[f], np.int16)
         bp_start = len(entries)
         if not active:
             return None
         idx = np.array([n.idx for n in active], np.int32)
+        # compallsen=no: acmod scores only the senones of the active HMMs
+        # (fsg_search_sen_active, src/fsg_search.c:310-325), so the caller scores the frame
+        scr = np.ascontiguousarray(senscr(f, senid[idx]) if callable(senscr) else senscr[f], np.int16)
         L.orc_hmm_vit_eval_many(model._m, scr.ctypes.data, len(idx), idx.ctypes.data,
                                 senid.ctypes.data, tmat.ctypes.data, score.ctypes.data,
                                 hist.ctypes.data, out_score.ctypes.data, out_hist.ctypes.data,

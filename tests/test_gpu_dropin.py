@@ -251,3 +251,34 @@ def test_goforward_from_words_with_product_glue(gpu_en, oracle_mod):
     s.free()
     g.free()
     lex.free()
+
+
+def test_default_configuration_scores_through_the_gpu_scorer(gpu_en, orc_en, oracle_mod):
+    """The reference's DEFAULT configuration (compallsen=no) end to end with the GPU scorer: every
+    frame of both passes is scored by vt->frame_eval with the active senone list acmod would
+    pass (rebuilt per frame in the first pass, only growing in the second), the top-N history
+    carried over the rewind; the searches are the restated ones of the oracle test.  The phone
+    scores must be the ones the real library printed (compallsen=no)."""
+    from tests.test_oracle_e2e_goforward import (REF_SCORES_DEFAULT, REF_WORDS, _parse_ref,
+                                                 default_configuration_alignment,
+                                                 goforward_features)
+    feats = goforward_features(oracle_mod)
+    g = ssw.PtmMgau(gpu_en)
+    g.reset_hist()
+    g.frame_idx = 0
+
+    def eval_frame(f, feat, lst):
+        row = g.frame_eval(feat, f, compallsen=False, senone_active=lst)
+        g.frame_idx = f + 1              # acmod_advance
+        return row
+
+    def rewind():
+        g.frame_idx = 0                  # acmod_rewind
+
+    seg, ph_start, ph_dur, ph_score = default_configuration_alignment(
+        oracle_mod, orc_en, feats, eval_frame, rewind)
+    assert [(w, s, e - s + 1) for (w, s, e, _) in seg] == [(w, s, d) for (w, s, d, _) in REF_WORDS]
+    ref = _parse_ref()
+    assert [(int(a), int(b)) for a, b in zip(ph_start, ph_dur)] == [(r[1], r[2]) for r in ref]
+    assert [int(x) for x in ph_score] == REF_SCORES_DEFAULT
+    g.free()

@@ -168,3 +168,128 @@ def test_history_sensitivity_of_goforward(oracle_mod, orc_en):
             differ.append(t)
     orc_en.ptm_reset()
     assert len(differ) == 1, differ
+
+
+# SURVEY.md Appendix C, compallsen=no (the reference's DEFAULT configuration): same boundaries,
+# these phone scores
+REF_SCORES_DEFAULT = [-67, -49, -56, -100, -47, -54, -43, -59, -35, -207, -53, -127, -42, -65,
+                      -136, -67, -141, -379]
+
+
+def default_configuration_alignment(O, m, feats, eval_frame, rewind):
+    """The reference's default is compallsen=no: acmod scores only the senones of the active
+    HMMs, through the uint8 delta list of acmod_flags2list (src/acmod.c:947-999), and the scorer
+    normalises over that set.  The first pass clears and rebuilds the set every frame
+    (fsg_search_sen_active); the second pass never clears it (state_align_search_step only
+    activates, src/state_align_search.c:185-188), so it starts from the first pass's last set
+    and grows; the top-N history carries over the rewind.  Both searches are restated here
+    around a per-frame scorer `eval_frame(frame, feature row, delta list) -> int16 [n_sen]`
+    (which also advances the scorer's frame index, as acmod_advance does); `rewind()` is
+    acmod_rewind.  Returns (first-pass segmentation, phone start, duration, score)."""
+    import ctypes as C
+    from oracle import fsg_oracle as F
+    d = os.path.join(MODEL_ROOT, "en-us")
+    lex = F.Lexicon(m, os.path.join(d, "dict.txt"), os.path.join(d, "noisedict.txt"))
+    T = len(feats)
+    n_words32 = (m.n_sen + 31) // 32
+    vec = np.zeros(n_words32, np.uint32)
+
+    def set_bits(sen):
+        for s_ in np.unique(np.asarray(sen).ravel()):
+            vec[int(s_) >> 5] |= np.uint32(1 << (int(s_) & 31))
+
+    def score(f):
+        return eval_frame(f, feats[f], O.flags2list(vec, m.n_sen))
+
+    # ---- first pass: the active set is rebuilt from the active HMMs every frame
+    def first_pass_scores(f, sen):
+        vec[:] = 0
+        set_bits(sen)
+        return score(f)
+
+    seg = F.first_pass(m, lex, "go forward ten meters".split(), first_pass_scores, n_frames=T)
+    # ---- second pass (decoder_alignment): rewind, constrained windows, growing active set
+    words = [(w, s, e - s + 1) for (w, s, e, _) in seg]
+    phones = populate(O, m, words)
+    n = len(phones)
+    senid = np.ascontiguousarray(m.sseq[[p[1] for p in phones]], np.uint16)
+    tmat = np.array([p[2] for p in phones], np.int16)
+    wstart = np.array([words[p[3]][1] for p in phones])
+    wdur = np.array([words[p[3]][2] for p in phones])
+    sf = np.where(wstart > 0, wstart, 0)
+    ef = np.where(wdur > 0, wstart + wdur, 2**31 - 1)
+    W = -(1 << 29)
+    sc = np.full((n, 3), W, np.int32)
+    hi = np.full((n, 3), -1, np.int32)
+    osc = np.full(n, W, np.int32)
+    ohi = np.full(n, -1, np.int32)
+    best = np.full(n, W, np.int32)
+    frame_of = np.full(n, -1, np.int64)
+    L = O.lib()
+    L.orc_hmm_vit_eval_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8
+    L.orc_hmm_vit_eval_many.restype = None
+    rewind()                               # acmod_rewind
+    sc[0, 0], hi[0, 0], frame_of[0] = 0, 0, 0     # state_align_search_start: hmm_enter(hmms, 0, 0, 0)
+    tokens = np.full((T, n * 3, 2), -1, np.int64)
+    for f in range(T):
+        act = np.nonzero(frame_of == f)[0]
+        set_bits(senid[act])               # activate only: the set keeps every earlier bit
+        row = score(f)
+        idx = np.nonzero(frame_of >= f)[0].astype(np.int32)
+        L.orc_hmm_vit_eval_many(m._m, row.ctypes.data, len(idx), idx.ctypes.data, senid.ctypes.data,
+                                tmat.ctypes.data, sc.ctypes.data, hi.ctypes.data, osc.ctypes.data,
+                                ohi.ctypes.data, best.ctypes.data)
+        nf = f + 1
+        for i in idx:                      # prune_hmms
+            if nf <= ef[i]:
+                frame_of[i] = nf
+        for i in range(n - 1):             # phone_transition
+            if frame_of[i] != nf or nf < sf[i + 1]:
+                continue
+            if frame_of[i + 1] < f or osc[i] > sc[i + 1, 0]:
+                sc[i + 1, 0], hi[i + 1, 0], frame_of[i + 1] = osc[i], ohi[i], nf
+        for i in np.nonzero(frame_of >= f)[0]:      # record_transitions
+            for j in range(3):
+                tokens[f, i * 3 + j] = (hi[i, j], sc[i, j])
+                hi[i, j] = i * 3 + j
+    # state_align_search_finish
+    last_id, last_sc = int(ohi[n - 1]), int(osc[n - 1])
+    assert last_id != -1
+    cur_id = last_id
+    last_frame = T
+    st = np.zeros((n * 3, 3), np.int64)
+    for cf in range(T - 2, -1, -1):
+        cid, csc = tokens[cf, cur_id]
+        assert cid != -1
+        if cid != last_id:
+            st[last_id] = (cf + 1, last_frame - (cf + 1), last_sc - csc)
+            last_id, last_sc, last_frame = int(cid), int(csc), cf + 1
+        cur_id = int(cid)
+    st[0, 0], st[0, 1] = 0, last_frame
+    ph_start = st[0::3, 0]
+    ph_dur = st.reshape(n, 3, 3)[:, :, 1].sum(1)
+    ph_score = st.reshape(n, 3, 3)[:, :, 2].sum(1)
+    return seg, ph_start, ph_dur, ph_score
+
+
+def test_default_configuration_scores(oracle_mod):
+    """Appendix C records the phone scores the real library printed in its default
+    configuration (compallsen=no); the oracle's per-frame scorer with active lists, driven by
+    the restated searches, reproduces them."""
+    O = oracle_mod
+    m = O.Model(os.path.join(MODEL_ROOT, "en-us"))
+    feats = goforward_features(O)
+    m.ptm_reset()
+    m.ptm_set_frame_idx(0)
+
+    def eval_frame(f, feat, lst):
+        row = m.ptm_frame_eval(feat, f, compallsen=False, senone_active=lst)
+        m.ptm_set_frame_idx(f + 1)
+        return row
+
+    seg, ph_start, ph_dur, ph_score = default_configuration_alignment(
+        O, m, feats, eval_frame, lambda: m.ptm_set_frame_idx(0))
+    assert [(w, s, e - s + 1) for (w, s, e, _) in seg] == [(w, s, dd) for (w, s, dd, _) in REF_WORDS]
+    ref = _parse_ref()
+    assert [(int(a), int(b)) for a, b in zip(ph_start, ph_dur)] == [(r[1], r[2]) for r in ref]
+    assert [int(x) for x in ph_score] == REF_SCORES_DEFAULT
