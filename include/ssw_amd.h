@@ -287,6 +287,16 @@ ssw_alignment_set_t *ssw_forced_align_batch(ssw_model_t *m, const ssw_dict_t *d,
                                             const int32_t *utt_off, int32_t n_utts,
                                             const int32_t *word_off, const char *const *words,
                                             void *stream);
+/* The same from FEATURES: scores the batch's feature rows in HBM (d_feats float32
+ * [n_frames][39], e.g. from ssw_feat_batch) with `scorer` into a workspace the model keeps,
+ * then ssw_forced_align_batch -- decoder_start_utt .. decoder_alignment for a batch, minus the
+ * MFCC front end, in one call. */
+ssw_alignment_set_t *ssw_align_text_batch(ssw_model_t *m, const ssw_dict_t *d,
+                                          const ssw_first_pass_config_t *cfg, int scorer,
+                                          const float *d_feats, int32_t n_frames,
+                                          const int32_t *utt_off, int32_t n_utts,
+                                          const int32_t *word_off, const char *const *words,
+                                          void *stream);
 int32_t ssw_alignment_set_status(const ssw_alignment_set_t *a, int32_t utt);
 /* each returns the number of entries and points the outputs (any may be NULL) at arrays owned
  * by the set: words -> dictionary ids; phones -> CI phone id and parent word index;

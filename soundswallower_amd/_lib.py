@@ -126,6 +126,8 @@ def lib() -> C.CDLL:
     L.ssw_first_pass_batch.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp]
     L.ssw_forced_align_batch.restype = vp
     L.ssw_forced_align_batch.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp]
+    L.ssw_align_text_batch.restype = vp
+    L.ssw_align_text_batch.argtypes = [vp, vp, vp, C.c_int, vp, i32, vp, i32, vp, vp, vp]
     L.ssw_alignment_set_status.restype = i32
     L.ssw_alignment_set_status.argtypes = [vp, i32]
     for fn in (L.ssw_alignment_set_words, L.ssw_alignment_set_states):

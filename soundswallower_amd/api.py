@@ -551,6 +551,25 @@ def forced_align_batch(model: Model, lex: Lexicon, d_senscr, utt_off, texts, cfg
     return AlignmentSet(L, h, lex)
 
 
+def align_text_batch(model: Model, lex: Lexicon, d_feats, utt_off, texts, cfg=None,
+                     scorer=SCORER_PTM, stream=None) -> AlignmentSet:
+    """ssw_align_text_batch: feature rows in HBM + texts -> alignments (scoring, first pass,
+    populate, constrained state alignment, propagate) in one C call."""
+    off = np.ascontiguousarray(utt_off, np.int32)
+    n_utts = len(off) - 1
+    word_off = np.zeros(n_utts + 1, np.int32)
+    word_off[1:] = np.cumsum([len(t) for t in texts])
+    flat = [w.encode() for t in texts for w in t]
+    arr = (C.c_char_p * max(1, len(flat)))(*flat)
+    L = _lib.lib()
+    h = L.ssw_align_text_batch(model._m, lex._d, None if cfg is None else C.byref(cfg), scorer,
+                               _ptr(d_feats), int(off[-1]), _ptr(off), n_utts, _ptr(word_off), arr,
+                               _ptr(stream))
+    if not h:
+        raise SswError("ssw_align_text_batch: " + _lib.last_error())
+    return AlignmentSet(L, h, lex)
+
+
 def forced_alignment(model: Model, lex: Lexicon, d_senscr, utt_off, texts, cfg=None, stream=None):
     """forced_align_batch, unpacked: one dict per utterance, None where it could not be aligned."""
     s = forced_align_batch(model, lex, d_senscr, utt_off, texts, cfg=cfg, stream=stream)

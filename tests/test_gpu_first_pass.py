@@ -183,6 +183,10 @@ def test_text_and_audio_to_the_reference_json(oracle_mod, gpu_en):
     with pytest.raises(ssw.SswError, match="no alignment"):
         aset.json(1)
     aset.free()
+    # ... and from the feature rows in one call (scores kept in the model's workspace)
+    aset = ssw.align_text_batch(gpu_en, lex, d_feats, off, texts)
+    assert aset.json(0) == line and aset.status(1) == 1
+    aset.free()
     lex.free()
 
 
