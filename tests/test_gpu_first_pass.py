@@ -287,3 +287,24 @@ def test_search_parameters_reach_the_search(oracle_mod, gpu_fr, orc_fr, kw):
             n_ok += 1
             assert g is not None and [(w, s, s + dd - 1, x) for (w, s, dd, x) in g] == want, (kw, t)
     assert n_ok >= 3
+
+
+def test_edge_shapes(oracle_mod, gpu_en, orc_en):
+    """An empty text (the grammar is one state with its filler loops), an utterance without
+    frames in the middle of a batch, one-frame and three-frame audio, a one-word text."""
+    F, olex = _olex(oracle_mod, orc_en, "en-us")
+    lex = _lex(gpu_en, "en-us")
+    rng = np.random.default_rng(3)
+    sil = synth_scores(F, orc_en, olex, [], 1, orc_en.n_sen)          # <sil> only
+    one = synth_scores(F, orc_en, olex, ["go"], 2, orc_en.n_sen)
+    texts = [[], ["go"], ["go"], ["go", "forward"], ["go"], []]
+    scores = [sil, one, np.zeros((0, orc_en.n_sen), np.int16), one[:1], one[:3], one]
+    got = _first_pass(gpu_en, lex, scores, texts)
+    for t, sc, g in zip(texts, scores, got):
+        want = F.first_pass(orc_en, olex, t, sc) if len(sc) else None
+        if want is None:
+            assert g is None, (t, len(sc))
+        else:
+            assert g is not None and [(w, s, s + d - 1, x) for (w, s, d, x) in g] == want, (t, len(sc))
+    assert got[0] is not None and all(w == "<sil>" for (w, _, _, _) in got[0])
+    assert got[1] is not None and got[2] is None
