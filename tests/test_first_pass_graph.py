@@ -12,12 +12,13 @@ from soundswallower_amd.synth import lcg_uniform
 from tests.conftest import MODEL_ROOT
 
 
-def canon_oracle(F, O, m, lex, words):
+def canon_oracle(F, O, m, lex, words, cfg=None):
+    cfg = cfg or F.Config
     lmath = O.Logmath(1.0001, 0)
-    lw = np.float32(F.Config.lw)
-    pip = int(np.float32(lmath.log(F.Config.pip)) * lw) >> 10
-    wip = int(np.float32(lmath.log(F.Config.wip)) * lw) >> 10
-    arcs = F.build_fsg(lex, words, lmath, F.Config)
+    lw = np.float32(cfg.lw)
+    pip = int(np.float32(lmath.log(cfg.pip)) * lw) >> 10
+    wip = int(np.float32(lmath.log(cfg.wip)) * lw) >> 10
+    arcs = F.build_fsg(lex, words, lmath, cfg)
     nodes, roots = F.build_lextree(m, lex, arcs, wip, pip)
     parent = {}
     state_of = {}
@@ -49,8 +50,8 @@ def canon_oracle(F, O, m, lex, words):
     return sorted(out, key=repr)
 
 
-def canon_product(lexp, m, words):
-    nodes, beams = lexp.first_pass_graph(words)
+def canon_product(lexp, m, words, cfg=None):
+    nodes, beams = lexp.first_pass_graph(words, cfg=cfg)
     keys = []
     for n in nodes:
         fl = int(n["flags"])
@@ -151,3 +152,19 @@ def test_alternates_pronounced_alike_are_marked(both):
     assert words.index("abus(2)") < words.index("abus")
     en_nodes, _ = both["en-us"][4].first_pass_graph(["go", "forward"])
     assert not any(n["flags"] & 8 for n in en_nodes)
+
+
+@pytest.mark.parametrize("kw", [dict(use_filler=0), dict(use_altpron=0),
+                                dict(lw=9.5, wip=0.2, pip=0.5, silprob=0.1, fillprob=1e-3),
+                                dict(use_filler=0, use_altpron=0)])
+def test_graph_follows_the_configuration(oracle_mod, both, kw):
+    """fsgusefiller / fsgusealtpron change which links exist, lw / wip / pip / silprob / fillprob
+    the entry penalties: same graphs as the oracle under the same settings (fr-fr)."""
+    F, mo, lo, mp, lp = both["fr-fr"]
+    names = {"use_filler": "fsgusefiller", "use_altpron": "fsgusealtpron"}
+    ocfg = type("Cfg", (F.Config,), {names.get(k, k): (bool(v) if k in names else v)
+                                     for k, v in kw.items()})
+    cfg = lp.first_pass_config(**kw)
+    for text in TEXTS["fr-fr"]:
+        words = text.split()
+        assert canon_product(lp, mp, words, cfg)[0] == canon_oracle(F, oracle_mod, mo, lo, words, ocfg), (kw, text)
