@@ -308,3 +308,37 @@ def test_edge_shapes(oracle_mod, gpu_en, orc_en):
             assert g is not None and [(w, s, s + d - 1, x) for (w, s, d, x) in g] == want, (t, len(sc))
     assert got[0] is not None and all(w == "<sil>" for (w, _, _, _) in got[0])
     assert got[1] is not None and got[2] is None
+
+
+def test_full_size_properties(gpu_en):
+    """BASELINE-sized utterances (1000 frames, texts of 25 words; 64 of them here) from features
+    to alignments in one call, checked through what the domain guarantees whatever the scores:
+    the words are the text's (fillers and alternates aside), word / phone / state entries tile
+    the utterance without gaps, every phone lies inside its word and every state inside its
+    phone, scores add up level by level (alignment_propagate)."""
+    import sys
+    from tests.conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_first_pass import build_workload
+    lex = _lex(gpu_en, "en-us")
+    utts, frames = 64, 1000
+    texts, feats, _ = build_workload(ssw, gpu_en, lex, utts, frames, 25)
+    off = (np.arange(utts + 1) * frames).astype(np.int32)
+    aset = ssw.align_text_batch(gpu_en, lex, torch.from_numpy(feats).cuda(), off, texts)
+    for u in range(utts):
+        a = aset.utterance(u)
+        assert a is not None, u
+        spoken = [w.split("(")[0] for w in a["words"] if not w.startswith(("<", "["))]
+        assert spoken == texts[u]
+        for lvl in ("word_al", "phone_al", "state_al"):
+            al = a[lvl]
+            assert al[0, 0] == 0 and int(al[:, 1].sum()) == frames
+            assert np.array_equal(al[1:, 0], al[:-1, 0] + al[:-1, 1])
+        w, p, s = a["word_al"], a["phone_al"], a["state_al"]
+        par = a["parent"]
+        assert np.all(p[:, 0] >= w[par, 0]) and np.all(p[:, 0] + p[:, 1] <= w[par, 0] + w[par, 1])
+        assert np.array_equal(np.bincount(par, weights=p[:, 2], minlength=len(w)).astype(np.int64),
+                              w[:, 2].astype(np.int64))
+        assert np.array_equal(s[:, 2].reshape(-1, 3).sum(1), p[:, 2])
+        assert np.array_equal(s[0::3, 0], p[:, 0])
+    aset.free()
