@@ -191,16 +191,17 @@ def test_text_and_audio_to_the_reference_json(oracle_mod, gpu_en):
 
 
 def test_long_texts_use_the_wider_kernels(oracle_mod, gpu_en, orc_en):
-    """Texts of 60 and 150 words: more than 512 / 1024 phone-tree HMMs, i.e. the 1024-thread
-    instances with one and two HMMs per thread; same results as the oracle."""
+    """Texts of 60, 150 and 330 words: more than 512 / 1024 / 2048 phone-tree HMMs, i.e. the
+    1024-thread instances with one, two and four HMMs per thread; same results as the oracle."""
     F, olex = _olex(oracle_mod, orc_en, "en-us")
     lex = _lex(gpu_en, "en-us")
     vocab = [w for w in olex.order[:olex.filler_start] if "(" not in w]
     u = lcg_uniform(31, 400)
     texts = [[vocab[int(x * len(vocab))] for x in u[:60]],
-             [vocab[int(x * len(vocab))] for x in u[100:250]]]
-    for t in texts:
-        assert len(lex.first_pass_graph(t)[0]) > (512 if len(t) == 60 else 1024)
+             [vocab[int(x * len(vocab))] for x in u[100:250]],
+             [vocab[int(x * len(vocab))] for x in np.concatenate([u, u[::-1]])[:330]]]
+    for t, least in zip(texts, (512, 1024, 2048)):
+        assert len(lex.first_pass_graph(t)[0]) > least
     scores = [synth_scores(F, orc_en, olex, t, 5 + i, orc_en.n_sen, sil_p=0.2)
               for i, t in enumerate(texts)]
     got = _first_pass(gpu_en, lex, scores, texts)
@@ -228,6 +229,9 @@ def test_large_batch_equals_one_by_one(oracle_mod, gpu_en, orc_en):
     bad[50] = bad[50] + ["qqqqq"]
     with pytest.raises(ssw.SswError, match="Unknown word qqqqq"):
         _first_pass(gpu_en, lex, scores, bad)
+    # a text with more phone-tree HMMs than a workgroup can hold is refused, not truncated
+    with pytest.raises(ssw.SswError, match="phone-tree HMMs"):
+        _first_pass(gpu_en, lex, [scores[0]], [[vocab[int(x * len(vocab))] for x in lcg_uniform(5, 800)]])
 
 
 def test_alternates_pronounced_alike(oracle_mod, gpu_fr, orc_fr):
