@@ -449,6 +449,10 @@ build_one(builder_t *b, const ssw_model_t *m, const ssw_host_model_t *h, const s
                     for (q = g->parent[i]; q >= 0 && n_anc < 64; q = g->parent[base + q] < -1 ? -1 : g->parent[base + q])
                         anc[n_anc++] = q;
             }
+            if (n_mem >= 64 || n_anc >= 64) {
+                ssw_set_error("a word of the text has 64+ phones or 64+ alternates pronounced alike");
+                goto bad;
+            }
             L = n_anc + n_mem;
             for (j = 0; j < n_mem; ++j) {
                 int o;
