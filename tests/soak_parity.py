@@ -130,14 +130,104 @@ def soak_first_pass(a):
                       "differences": 0, "label_differences_among_identical_alternates": n_label}))
 
 
+def soak_text(a):
+    """decoder_alignment end to end: ssw_forced_align_batch (first pass, populate, constrained
+    state alignment, propagate) against the oracle's pipeline -- restated first pass, then
+    alignment_populate restated on the oracle's bin_mdef_phone_id_nearest with the first pass's
+    words and windows, then orc_state_align -- on random texts with synthetic scores."""
+    import torch
+    from oracle import fsg_oracle as F
+    from tests.test_gpu_first_pass import synth_scores
+    mdir = ssw.model_dir(a.model)
+    m = ssw.Model(mdir)
+    orc = O.Model(mdir)
+    lex = ssw.Lexicon(m, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
+    olex = F.Lexicon(orc, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
+    vocab = [w for w in olex.order[:olex.filler_start] if "(" not in w]
+    sil = orc.sil
+
+    def populate(words):
+        """alignment_populate (src/ps_alignment.c:132-247): [(word, start, dur)] -> ssid, tmat, word index"""
+        out = []
+        lc = sil
+        for i, (w, _, _) in enumerate(words):
+            p = olex.pron[w]
+            rc = olex.pron[words[i + 1][0]][0] if i < len(words) - 1 else sil
+            n = len(p)
+            for j in range(n):
+                if n == 1:
+                    pid = O.phone_id_nearest(orc, p[0], lc, rc, 3)
+                elif j == 0:
+                    pid = O.phone_id_nearest(orc, p[0], lc, p[1], 1)
+                elif j == n - 1:
+                    pid = O.phone_id_nearest(orc, p[j], p[j - 1], rc, 2)
+                else:
+                    pid = O.phone_id_nearest(orc, p[j], p[j - 1], p[j + 1], 0)
+                out.append((int(orc.phone_ssid[pid]), int(orc.phone_tmat[p[j]]), i))
+            lc = p[-1]
+        return out
+
+    rng = np.random.default_rng(4711)
+    t_end = time.time() + a.seconds
+    n_utts = n_frames = n_fail = n_batches = 0
+    while time.time() < t_end:
+        nb = int(rng.integers(1, 24))
+        texts, scores = [], []
+        for _ in range(nb):
+            words = [vocab[int(rng.integers(len(vocab)))] for _ in range(int(rng.integers(1, 10)))]
+            sc = synth_scores(F, orc, olex, words, int(rng.integers(1 << 30)), orc.n_sen,
+                              noise_lo=int(rng.choice([120, 60, 30])), sil_p=float(rng.random()))
+            if rng.random() < 0.1:
+                sc = sc[:int(len(sc) * rng.uniform(0.4, 0.95))]
+            texts.append(words)
+            scores.append(sc)
+        off = np.concatenate([[0], np.cumsum([len(s) for s in scores])]).astype(np.int32)
+        d = torch.from_numpy(np.ascontiguousarray(np.concatenate(scores), np.int16)).cuda()
+        aset = ssw.forced_align_batch(m, lex, d, off, texts)
+        for u, (t, sc) in enumerate(zip(texts, scores)):
+            seg = F.first_pass(orc, olex, t, sc)
+            got = aset.utterance(u)
+            if seg is None:
+                assert got is None and aset.status(u) == 1, t
+                n_fail += 1
+            else:
+                words = [(w, s, e - s + 1) for (w, s, e, _) in seg]
+                ph = populate(words)
+                senid = orc.sseq[[x[0] for x in ph]]
+                tmat = np.array([x[1] for x in ph], np.int16)
+                ws = np.array([words[x[2]][1] for x in ph], np.int32)
+                wd = np.array([words[x[2]][2] for x in ph], np.int32)
+                sf = np.where(ws > 0, ws, 0).astype(np.int32)
+                ef = np.where(wd > 0, ws + wd, 2**31 - 1).astype(np.int32)
+                init = np.stack([np.repeat(ws, 3), np.repeat(wd, 3), np.zeros(3 * len(ph), np.int32)], 1)
+                rv, st, php = orc.state_align(sc, senid, tmat, sf, ef, state_init=init.astype(np.int32))
+                if rv != 0:
+                    assert got is None and aset.status(u) == 2, t
+                    n_fail += 1
+                else:
+                    assert got is not None, t
+                    assert got["words"] == [w for (w, _, _) in words], t
+                    assert np.array_equal(got["state_al"], st), t
+                    assert np.array_equal(got["phone_al"], php), t
+                    assert np.array_equal(got["senid"], senid), t
+            n_utts += 1
+            n_frames += len(sc)
+        aset.free()
+        n_batches += 1
+    print(json.dumps({"mode": "text", "model": a.model, "batches": n_batches, "utterances": n_utts,
+                      "frames": n_frames, "not_aligned_on_both_sides": n_fail, "differences": 0}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--model", default="en-us")
-    ap.add_argument("--mode", default="ptm", choices=["ptm", "ms", "align", "first_pass"])
+    ap.add_argument("--mode", default="ptm", choices=["ptm", "ms", "align", "first_pass", "text"])
     a = ap.parse_args()
     if a.mode == "first_pass":
         return soak_first_pass(a)
+    if a.mode == "text":
+        return soak_text(a)
     if a.mode == "align":
         return soak_align(a)
     mdir = ssw.model_dir(a.model)
