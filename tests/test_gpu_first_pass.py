@@ -346,3 +346,24 @@ def test_full_size_properties(gpu_en):
         assert np.array_equal(s[:, 2].reshape(-1, 3).sum(1), p[:, 2])
         assert np.array_equal(s[0::3, 0], p[:, 0])
     aset.free()
+
+
+def test_french_recording_from_cepstra(oracle_mod, gpu_fr):
+    """The reference's second recording end to end (cepstra -> device features -> scores ->
+    first pass -> populate -> constrained alignment): the words, with the alternates the
+    reference picked, and their frames as it printed them (fr-fr PTM)."""
+    from tests.conftest import ROOT
+    pcm = np.fromfile(os.path.join(ROOT, "tests", "golden", "goforward_fr.raw"), dtype="<i2")
+    cep = oracle_mod.fe_mfcc(pcm, nfilt=20, lowerf=130, upperf=3700, lifter=22, remove_noise=True,
+                             transform="dct")
+    feats = gpu_fr.feat_batch(cep)
+    lex = _lex(gpu_fr, "fr-fr")
+    off = np.array([0, len(feats)], np.int32)
+    aset = ssw.align_text_batch(gpu_fr, lex, torch.from_numpy(feats).cuda(), off,
+                                ["avance de dix mètres".split()])
+    a = aset.utterance(0)
+    assert [(w, int(r[0]), int(r[1])) for w, r in zip(a["words"], a["word_al"])] == REF_FR
+    line = aset.json(0)
+    assert line.startswith('{"b":0.000,"d":2.400,"p":1.000,"t":"avance de dix mètres","w":[{"b":0.000,"d":0.320,')
+    assert '"t":"de(2)"' in line and '"t":"mètres(4)"' in line
+    aset.free()
