@@ -64,3 +64,60 @@ def shard_utterances_by_list(local_utts, world_size, rank):
     plan = [None] * world_size
     dist.all_gather_object(plan, [int(u) for u in local_utts])
     return plan
+
+
+def gather_text_alignments(local, local_utts, world_size: int, rank: int, device=None):
+    """All-gather alignments made from TEXT (forced_align_batch): unlike gather_alignments the
+    entry counts are not known in advance -- the first pass decides which fillers and alternates
+    each utterance contains -- so the ranks exchange their buffer lengths first, then one padded
+    all_gather of the flattened results.
+
+    local: one item per utterance of local_utts: None (not aligned) or a dict with int32 arrays
+    wid [n_w], word_al [n_w][3], cipid [n_p], parent [n_p], phone_al [n_p][3], state_al
+    [3 n_p][3] (AlignmentSet.utterance).  Returns a list indexed by global utterance id."""
+    import torch
+    import torch.distributed as dist
+
+    parts = []
+    for u, a in zip(local_utts, local):
+        if a is None:
+            parts.append(np.array([int(u), -1, 0], np.int32))
+            continue
+        n_w, n_p = len(a["wid"]), len(a["cipid"])
+        parts.append(np.concatenate([
+            np.array([int(u), n_w, n_p], np.int32), np.asarray(a["wid"], np.int32),
+            np.asarray(a["word_al"], np.int32).reshape(-1), np.asarray(a["cipid"], np.int32),
+            np.asarray(a["parent"], np.int32), np.asarray(a["phone_al"], np.int32).reshape(-1),
+            np.asarray(a["state_al"], np.int32).reshape(-1)]))
+    flat = np.concatenate(parts) if parts else np.zeros(0, np.int32)
+    n = torch.tensor([len(flat)], dtype=torch.int64)
+    if device is not None:
+        n = n.to(device)
+    lens = [torch.zeros_like(n) for _ in range(world_size)]
+    dist.all_gather(lens, n)
+    lens = [int(x.item()) for x in lens]
+    buf = np.zeros(max(max(lens), 1), np.int32)
+    buf[:len(flat)] = flat
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    bufs = [torch.empty_like(t) for _ in range(world_size)]
+    dist.all_gather(bufs, t)
+    out = {}
+    for r in range(world_size):
+        v = bufs[r].cpu().numpy()[:lens[r]]
+        pos = 0
+        while pos < len(v):
+            u, n_w, n_p = int(v[pos]), int(v[pos + 1]), int(v[pos + 2])
+            pos += 3
+            if n_w < 0:
+                out[u] = None
+                continue
+            a = {}
+            for key, cnt, cols in (("wid", n_w, 0), ("word_al", n_w, 3), ("cipid", n_p, 0),
+                                   ("parent", n_p, 0), ("phone_al", n_p, 3), ("state_al", 3 * n_p, 3)):
+                k = cnt * (cols or 1)
+                a[key] = v[pos:pos + k].reshape(cnt, cols).copy() if cols else v[pos:pos + k].copy()
+                pos += k
+            out[u] = a
+    return [out[u] for u in sorted(out)]

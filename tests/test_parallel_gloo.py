@@ -68,3 +68,56 @@ def test_gather_alignments_world2():
     for u, n in enumerate(n_states):
         exp = np.stack([np.arange(n) * (u + 1), np.full(n, u + 1), -np.arange(n) - u], 1)
         assert np.array_equal(np.array(got[u]), exp)
+
+
+def _text_worker(rank, world, port, n_utts, q):
+    import torch.distributed as dist
+    from soundswallower_amd.parallel import gather_text_alignments
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_utterances([100 + 7 * u for u in range(n_utts)], world)[rank]
+    local = [_fake_text_alignment(u) for u in mine]
+    full = gather_text_alignments(local, mine, world, rank)
+    if rank == 0:
+        q.put([None if a is None else {k: v.tolist() for k, v in a.items()} for a in full])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _fake_text_alignment(u):
+    """stand-in for AlignmentSet.utterance(u): sizes vary per utterance, one is not aligned"""
+    if u == 3:
+        return None
+    n_w, n_p = 2 + u % 3, 4 + u
+    r = np.random.default_rng(u)
+    return {"wid": r.integers(0, 1000, n_w).astype(np.int32),
+            "word_al": r.integers(-500, 500, (n_w, 3)).astype(np.int32),
+            "cipid": r.integers(0, 42, n_p).astype(np.int32),
+            "parent": np.sort(r.integers(0, n_w, n_p)).astype(np.int32),
+            "phone_al": r.integers(-500, 500, (n_p, 3)).astype(np.int32),
+            "state_al": r.integers(-500, 500, (3 * n_p, 3)).astype(np.int32)}
+
+
+@pytest.mark.timeout(120)
+def test_gather_text_alignments_world2():
+    """alignments from text have data-dependent sizes (fillers, alternates) and may be missing:
+    lengths first, then one padded all_gather; every rank ends with all of them in global order"""
+    n_utts = 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_text_worker, args=(r, 2, port, n_utts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=100)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(got) == n_utts
+    for u in range(n_utts):
+        want = _fake_text_alignment(u)
+        if want is None:
+            assert got[u] is None
+        else:
+            assert {k: v.tolist() for k, v in want.items()} == got[u]

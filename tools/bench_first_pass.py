@@ -131,18 +131,75 @@ def run(ssw, m, lex, torch, utts=256, frames=1000, words_per_text=25, reps=3, no
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--utts", type=int, default=256)
+    ap.add_argument("--utts", type=int, default=256, help="utterances in the whole job")
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--words", type=int, default=25)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--noise", type=float, default=0.3)
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for the gather (nccl = RCCL; gloo lets two "
+                         "ranks share one GPU on a 1-GPU box to exercise the multi-rank flow)")
+    ap.add_argument("--device", type=int, default=None, help="GPU to use (default LOCAL_RANK)")
     a = ap.parse_args()
     import torch
-    _lib.build()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if a.device is None else a.device
+    torch.cuda.set_device(local_rank)
+    if world == 1:
+        _lib.build()
+        mdir = ssw.model_dir("en-us")
+        m = ssw.Model(mdir)
+        lex = ssw.Lexicon(m, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
+        print(json.dumps(run(ssw, m, lex, torch, a.utts, a.frames, a.words, a.reps, a.noise)))
+        return
+    # launched as `python -m torch.distributed.run --nproc-per-node N tools/bench_first_pass.py`:
+    # the job's texts are dealt to the ranks, every rank scores and aligns its own, and the
+    # alignments (their sizes depend on the fillers and alternates found) are gathered once
+    import torch.distributed as dist
+    from soundswallower_amd.parallel import gather_text_alignments, shard_utterances
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if a.backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(a.backend)
+    if rank == 0:
+        _lib.build()
+    dist.barrier()
     mdir = ssw.model_dir("en-us")
-    m = ssw.Model(mdir)
+    m = ssw.Model(mdir, config={"device": local_rank})
     lex = ssw.Lexicon(m, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
-    print(json.dumps(run(ssw, m, lex, torch, a.utts, a.frames, a.words, a.reps, a.noise)))
+    texts, feats, _ = build_workload(ssw, m, lex, a.utts, a.frames, a.words, a.noise)  # same on all ranks
+    mine = shard_utterances([a.frames] * a.utts, world)[rank]
+    my_texts = [texts[u] for u in mine]
+    my_feats = np.concatenate([feats[u * a.frames:(u + 1) * a.frames] for u in mine])
+    off = (np.arange(len(mine) + 1) * a.frames).astype(np.int32)
+    d_feats = torch.from_numpy(my_feats).cuda()
+    best = 1e9
+    for _ in range(a.reps):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        aset = ssw.align_text_batch(m, lex, d_feats, off, my_texts)
+        res = [aset.utterance(k) for k in range(len(mine))]
+        aset.free()
+        full = gather_text_alignments(res, mine, world, rank,
+                                      device=torch.device("cuda", local_rank) if a.backend == "nccl" else None)
+        best = min(best, time.perf_counter() - t0)
+    t = torch.tensor([best], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        import zlib
+        ok = [x for x in full if x is not None]
+        crc = zlib.crc32(np.concatenate([np.concatenate([x["wid"], x["state_al"].reshape(-1)]) for x in ok]).tobytes())
+        tiles = all(int(x["word_al"][:, 1].sum()) == a.frames for x in ok)
+        print(json.dumps({
+            "workload": f"{a.utts} utterances x {a.frames} frames, texts of {a.words} words, en-us, "
+                        f"features + text -> alignments, sharded over {world} GPU(s), one gather",
+            "n_gpus": world, "wall_s": float(t.item()), "aligned": len(ok), "n_utts": a.utts,
+            "rtf": float(t.item()) / (a.utts * a.frames / 100.0),
+            "alignments_tile_their_utterances": bool(tiles), "alignment_crc32": crc}))
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":
