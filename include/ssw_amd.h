@@ -272,6 +272,20 @@ int ssw_first_pass_batch(ssw_model_t *m, const ssw_dict_t *d, const ssw_first_pa
                          int32_t n_utts, const int32_t *word_off, const char *const *words,
                          int32_t max_seg, int32_t *n_seg, ssw_word_seg_t *seg, void *stream);
 
+/* The first pass in two halves, for pipelines: ssw_first_pass_prepare builds the graphs of a
+ * batch of texts on the host (no device call; safe on another host thread while the GPU works
+ * on the previous batch), ssw_first_pass_run / ssw_forced_align_planned search them.  A plan
+ * can be run any number of times (e.g. the same texts against several recordings) and is
+ * freed by the caller. */
+typedef struct ssw_first_pass_plan_s ssw_first_pass_plan_t;
+ssw_first_pass_plan_t *ssw_first_pass_prepare(const ssw_model_t *m, const ssw_dict_t *d,
+                                              const ssw_first_pass_config_t *cfg, int32_t n_utts,
+                                              const int32_t *word_off, const char *const *words);
+void ssw_first_pass_plan_free(ssw_first_pass_plan_t *plan);
+int ssw_first_pass_run(ssw_model_t *m, const ssw_first_pass_plan_t *plan, const int16_t *d_senscr,
+                       int32_t n_frames, const int32_t *utt_off, int32_t max_seg, int32_t *n_seg,
+                       ssw_word_seg_t *seg, void *stream);
+
 /* decoder_alignment (src/decoder.c:737-798) for a batch: first pass, then alignment_add_word
  * with the first pass's word windows + alignment_populate, the state alignment constrained to
  * those windows (state_align_search_init / step / finish), alignment_propagate.  The result
@@ -287,6 +301,11 @@ ssw_alignment_set_t *ssw_forced_align_batch(ssw_model_t *m, const ssw_dict_t *d,
                                             const int32_t *utt_off, int32_t n_utts,
                                             const int32_t *word_off, const char *const *words,
                                             void *stream);
+/* ssw_forced_align_batch with the graphs prepared beforehand (ssw_first_pass_prepare) */
+ssw_alignment_set_t *ssw_forced_align_planned(ssw_model_t *m, const ssw_dict_t *d,
+                                              const ssw_first_pass_plan_t *plan,
+                                              const int16_t *d_senscr, int32_t n_frames,
+                                              const int32_t *utt_off, void *stream);
 /* The same from FEATURES: scores the batch's feature rows in HBM (d_feats float32
  * [n_frames][39], e.g. from ssw_feat_batch) with `scorer` into a workspace the model keeps,
  * then ssw_forced_align_batch -- decoder_start_utt .. decoder_alignment for a batch, minus the

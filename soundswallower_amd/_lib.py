@@ -126,6 +126,14 @@ def lib() -> C.CDLL:
     L.ssw_first_pass_batch.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp]
     L.ssw_forced_align_batch.restype = vp
     L.ssw_forced_align_batch.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp]
+    L.ssw_first_pass_prepare.restype = vp
+    L.ssw_first_pass_prepare.argtypes = [vp, vp, vp, i32, vp, vp]
+    L.ssw_first_pass_plan_free.argtypes = [vp]
+    L.ssw_first_pass_plan_free.restype = None
+    L.ssw_first_pass_run.restype = C.c_int
+    L.ssw_first_pass_run.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp]
+    L.ssw_forced_align_planned.restype = vp
+    L.ssw_forced_align_planned.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     L.ssw_align_text_batch.restype = vp
     L.ssw_align_text_batch.argtypes = [vp, vp, vp, C.c_int, vp, i32, vp, i32, vp, vp, vp]
     L.ssw_alignment_set_status.restype = i32

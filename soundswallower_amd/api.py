@@ -551,6 +551,46 @@ def forced_align_batch(model: Model, lex: Lexicon, d_senscr, utt_off, texts, cfg
     return AlignmentSet(L, h, lex)
 
 
+class FirstPassPlan:
+    """ssw_first_pass_plan_t: the graphs of a batch of texts, built on the host without touching
+    the device (ctypes releases the GIL: prepare the next batch on another thread while the GPU
+    works on this one)."""
+
+    def __init__(self, model: Model, lex: Lexicon, texts, cfg=None):
+        self._L = _lib.lib()
+        n_utts = len(texts)
+        word_off = np.zeros(n_utts + 1, np.int32)
+        word_off[1:] = np.cumsum([len(t) for t in texts])
+        flat = [w.encode() for t in texts for w in t]
+        arr = (C.c_char_p * max(1, len(flat)))(*flat)
+        self.n_utts = n_utts
+        self._p = self._L.ssw_first_pass_prepare(model._m, lex._d,
+                                                 None if cfg is None else C.byref(cfg), n_utts,
+                                                 _ptr(word_off), arr)
+        if not self._p:
+            raise SswError("ssw_first_pass_prepare: " + _lib.last_error())
+
+    def free(self):
+        if getattr(self, "_p", None):
+            self._L.ssw_first_pass_plan_free(self._p)
+            self._p = None
+
+    __del__ = free
+
+
+def forced_align_planned(model: Model, lex: Lexicon, plan: FirstPassPlan, d_senscr, utt_off,
+                         stream=None) -> AlignmentSet:
+    """ssw_forced_align_planned: forced_align_batch with the graphs prepared beforehand."""
+    off = np.ascontiguousarray(utt_off, np.int32)
+    assert len(off) - 1 == plan.n_utts
+    L = _lib.lib()
+    h = L.ssw_forced_align_planned(model._m, lex._d, plan._p, _ptr(d_senscr), int(off[-1]),
+                                   _ptr(off), _ptr(stream))
+    if not h:
+        raise SswError("ssw_forced_align_planned: " + _lib.last_error())
+    return AlignmentSet(L, h, lex)
+
+
 def align_text_batch(model: Model, lex: Lexicon, d_feats, utt_off, texts, cfg=None,
                      scorer=SCORER_PTM, stream=None) -> AlignmentSet:
     """ssw_align_text_batch: feature rows in HBM + texts -> alignments (scoring, first pass,

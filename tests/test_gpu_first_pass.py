@@ -225,6 +225,22 @@ def test_large_batch_equals_one_by_one(oracle_mod, gpu_en, orc_en):
     for i in range(64):
         assert got[i] == _first_pass(gpu_en, lex, [scores[i]], [texts[i]])[0], i
     assert sum(g is not None for g in got) > 48
+    # the same with the graphs prepared beforehand; a plan can be run again (other scores)
+    off = np.concatenate([[0], np.cumsum([len(s) for s in scores])]).astype(np.int32)
+    d = torch.from_numpy(np.ascontiguousarray(np.concatenate(scores), np.int16)).cuda()
+    plan = ssw.FirstPassPlan(gpu_en, lex, texts)
+    a1 = ssw.forced_align_planned(gpu_en, lex, plan, d, off)
+    a2 = ssw.forced_align_batch(gpu_en, lex, d, off, texts)
+    a3 = ssw.forced_align_planned(gpu_en, lex, plan, d, off)
+    for i in range(64):
+        u1, u2, u3 = a1.utterance(i), a2.utterance(i), a3.utterance(i)
+        assert (u1 is None) == (u2 is None) == (u3 is None) == (got[i] is None)
+        if u1 is not None:
+            assert u1["words"] == u2["words"] == u3["words"] == [w for (w, _, _, _) in got[i]]
+            assert np.array_equal(u1["state_al"], u2["state_al"]) and np.array_equal(u1["state_al"], u3["state_al"])
+    for x in (a1, a2, a3):
+        x.free()
+    plan.free()
     bad = [list(t) for t in texts]
     bad[50] = bad[50] + ["qqqqq"]
     with pytest.raises(ssw.SswError, match="Unknown word qqqqq"):

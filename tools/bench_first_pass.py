@@ -129,8 +129,63 @@ def run(ssw, m, lex, torch, utts=256, frames=1000, words_per_text=25, reps=3, no
     }
 
 
+def run_pipeline(ssw, m, lex, torch, utts, frames, words_per_text, batches, noise=0.3):
+    """Steady state of a stream of batches: a host thread prepares the next batch's graphs
+    (ssw_first_pass_prepare: no device call, the GIL is released inside the C call) while the
+    GPU scores and searches the current one.  Returns ms per batch, pipelined and not."""
+    import threading
+    texts, feats, _ = build_workload(ssw, m, lex, utts, frames, words_per_text, noise)
+    off = (np.arange(utts + 1) * frames).astype(np.int32)
+    d_feats = torch.from_numpy(feats).cuda()
+    d_scr = torch.empty((len(feats), m.n_sen), dtype=torch.int16, device="cuda")
+
+    def gpu_part(plan):
+        m.score_batch_device(d_feats, len(feats), off, d_scr)
+        aset = ssw.forced_align_planned(m, lex, plan, d_scr, off)
+        n = sum(aset.status(k) == 0 for k in range(utts))
+        aset.free()
+        return n
+
+    # warm-up, then the two ways
+    p0 = ssw.FirstPassPlan(m, lex, texts)
+    gpu_part(p0)
+    p0.free()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(batches):
+        plan = ssw.FirstPassPlan(m, lex, texts)
+        ok = gpu_part(plan)
+        plan.free()
+    serial = (time.perf_counter() - t0) / batches
+    box = {}
+
+    def prep():
+        box["plan"] = ssw.FirstPassPlan(m, lex, texts)
+
+    prep()
+    t0 = time.perf_counter()
+    for _ in range(batches):
+        cur = box["plan"]
+        th = threading.Thread(target=prep)
+        th.start()
+        ok = gpu_part(cur)
+        th.join()
+        cur.free()
+    piped = (time.perf_counter() - t0) / batches
+    box["plan"].free()
+    audio_s = utts * frames / 100.0
+    return {"workload": f"stream of batches of {utts} utterances x {frames} frames, texts of "
+                        f"{words_per_text} words: features + text -> alignments",
+            "batches": batches, "aligned_in_last_batch": ok,
+            "ms_per_batch_serial": serial * 1e3, "ms_per_batch_pipelined": piped * 1e3,
+            "rtf_serial": serial / audio_s, "rtf_pipelined": piped / audio_s}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="N > 0: stream N batches, the next batch's graphs prepared on a host "
+                         "thread while the GPU works on the current one")
     ap.add_argument("--utts", type=int, default=256, help="utterances in the whole job")
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--words", type=int, default=25)
@@ -151,7 +206,11 @@ def main():
         mdir = ssw.model_dir("en-us")
         m = ssw.Model(mdir)
         lex = ssw.Lexicon(m, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
-        print(json.dumps(run(ssw, m, lex, torch, a.utts, a.frames, a.words, a.reps, a.noise)))
+        if a.pipeline > 0:
+            print(json.dumps(run_pipeline(ssw, m, lex, torch, a.utts, a.frames, a.words, a.pipeline,
+                                          a.noise)))
+        else:
+            print(json.dumps(run(ssw, m, lex, torch, a.utts, a.frames, a.words, a.reps, a.noise)))
         return
     # launched as `python -m torch.distributed.run --nproc-per-node N tools/bench_first_pass.py`:
     # the job's texts are dealt to the ranks, every rank scores and aligns its own, and the
