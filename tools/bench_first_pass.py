@@ -104,8 +104,13 @@ def run(ssw, m, lex, torch, utts=256, frames=1000, words_per_text=25, reps=3, no
         t3 = time.perf_counter()
         res = [aset.utterance(k) for k in range(utts)]
         aset.free()
-        cur = {"score_s": t1 - t0, "first_pass_s": t2 - t1, "alignment_s": t3 - t2}
-        if best is None or cur["score_s"] + cur["alignment_s"] < best["score_s"] + best["alignment_s"]:
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        one = ssw.align_text_batch(m, lex, d_feats, off, texts)    # everything in one call: the
+        t5 = time.perf_counter()                                   # graphs are built while the GPU scores
+        one.free()
+        cur = {"score_s": t1 - t0, "first_pass_s": t2 - t1, "alignment_s": t3 - t2, "one_call_s": t5 - t4}
+        if best is None or cur["one_call_s"] < best["one_call_s"]:
             best = cur
     segs = lex.first_pass(d_scr, off, texts)
     done = [s for s in segs if s is not None]
@@ -114,7 +119,7 @@ def run(ssw, m, lex, torch, utts=256, frames=1000, words_per_text=25, reps=3, no
     aligned = sum(1 for r in res if r is not None)
     tiles = all(int(r["word_al"][:, 1].sum()) == frames for r in res if r is not None)
     audio_s = utts * frames / 100.0
-    wall = best["score_s"] + best["alignment_s"]
+    wall = best["one_call_s"]
     return {
         "workload": f"{utts} utterances x {frames} frames, texts of {words_per_text} words, en-us; "
                     f"synthetic audio following the text: scoring, then decoder_alignment from "
@@ -122,6 +127,7 @@ def run(ssw, m, lex, torch, utts=256, frames=1000, words_per_text=25, reps=3, no
         "hmms_per_text": nodes_per_text,
         "score_ms": best["score_s"] * 1e3, "first_pass_ms": best["first_pass_s"] * 1e3,
         "decoder_alignment_ms": best["alignment_s"] * 1e3,
+        "features_to_alignments_ms": best["one_call_s"] * 1e3,
         "first_pass_completed": len(done), "first_pass_words_equal_text": same_words,
         "aligned": aligned, "alignments_tile_their_utterances": bool(tiles), "n_utts": utts,
         "rtf": wall / audio_s,
