@@ -110,8 +110,7 @@ def run(ssw, m, lex, torch, utts=256, frames=1000, words_per_text=25, reps=3, no
         t5 = time.perf_counter()                                   # graphs are built while the GPU scores
         one.free()
         cur = {"score_s": t1 - t0, "first_pass_s": t2 - t1, "alignment_s": t3 - t2, "one_call_s": t5 - t4}
-        if best is None or cur["one_call_s"] < best["one_call_s"]:
-            best = cur
+        best = cur if best is None else {k: min(best[k], cur[k]) for k in cur}   # per stage
     segs = lex.first_pass(d_scr, off, texts)
     done = [s for s in segs if s is not None]
     same_words = sum(1 for s, t in zip(segs, texts) if s is not None and
