@@ -583,6 +583,15 @@ graphs_build_serial(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_p
     return g;
 }
 
+/* host threads for per-utterance work: SSW_HOST_THREADS, default 8 */
+int
+ssw_host_threads(void)
+{
+    const char *e = getenv("SSW_HOST_THREADS");
+    int n = e ? atoi(e) : 8;
+    return n < 1 ? 1 : n;
+}
+
 /* Texts are independent: large batches are built by a few threads, each over a contiguous
  * range of utterances, and the pieces are concatenated (indices are local to an utterance;
  * only the offsets tables need rebasing). */
@@ -630,12 +639,15 @@ ssw_fp_graphs_t *
 ssw_fp_graphs_build(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_pass_config_t *cfg,
                     int32_t n_utts, const int32_t *word_off, const char *const *words)
 {
-    enum { MAX_THR = 8, MIN_PER_THR = 16 };
+    enum { MAX_THR = 32, MIN_PER_THR = 16 };
     build_job_t job[MAX_THR];
     pthread_t thr[MAX_THR];
     int started[MAX_THR];
     ssw_fp_graphs_t *g, total;
     int n_thr = n_utts / MIN_PER_THR, t, ok = 1, u;
+    const int cap = ssw_host_threads();
+    if (n_thr > cap)
+        n_thr = cap;
     if (n_thr > MAX_THR)
         n_thr = MAX_THR;
     if (n_thr < 2)

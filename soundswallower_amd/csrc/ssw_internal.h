@@ -117,6 +117,7 @@ ssw_fp_graphs_t *ssw_fp_graphs_build(const ssw_model_t *m, const struct ssw_dict
                                      const ssw_first_pass_config_t *cfg, int32_t n_utts,
                                      const int32_t *word_off, const char *const *words);
 void ssw_fp_graphs_free(ssw_fp_graphs_t *g);
+int ssw_host_threads(void);
 
 #ifdef __cplusplus
 }
