@@ -200,3 +200,23 @@ def test_clustered_sendump_is_expanded_with_the_reference_rule(orc_en, tmp_path)
                   tmat=os.path.join(src, "transition_matrices"), config={"device": -2})
     got = m.table("ptm_mixw").reshape(expect.shape)
     assert np.array_equal(got, expect)
+
+
+def test_first_pass_plan_is_host_only(lib):
+    """ssw_first_pass_prepare needs no device (it can run while the GPU is busy, or on a box
+    without one); running the plan does, and says so."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    d = os.path.join(MODEL_ROOT, "en-us")
+    m = ssw.Model(d, config={"device": -2})
+    lex = ssw.Lexicon(m, os.path.join(d, "dict.txt"), os.path.join(d, "noisedict.txt"))
+    plan = ssw.FirstPassPlan(m, lex, [["go", "forward"], ["ten", "meters"]] * 20)   # threaded build
+    assert plan.n_utts == 40
+    with pytest.raises(ssw.SswError, match="no CPU fallback"):
+        ssw.forced_align_planned(m, lex, plan, 0, np.arange(41, dtype=np.int32) * 10)
+    plan.free()
+    with pytest.raises(ssw.SswError, match="Unknown word"):
+        ssw.FirstPassPlan(m, lex, [["go"]] * 39 + [["zzzzz"]])
+    with pytest.raises(ssw.SswError, match="no CPU fallback"):
+        ssw.align_text_batch(m, lex, 0, [0, 10], [["go"]])
+    lex.free()
