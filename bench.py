@@ -10,13 +10,22 @@ over one batch of synthetic features already resident in HBM: BASELINE.json conf
 utterances -- the path partitions by utterance, there is no data-path collective -- and the
 reported value is the whole-job rate over the max-over-ranks time (weak scaling).
 
-Prints ONE JSON line on rank 0, including `roofline` (dominant kernel, HIP-event timed on the
-launch stream) and `cpu_baseline` (the CPU oracle timed on a bounded sample of the same
-workload on the host cores of this box).
+Prints ONE JSON line on rank 0, including
+  `roofline`     dominant kernels, HIP-event timed on the launch stream;
+  `cpu_baseline` the CPU oracle timed on a bounded sample of the same workload on the host
+                 cores of this box, one core and all cores (N = 1 only);
+  `config5`      BASELINE.json configs[4] at every N: 2048 utterances x 1000 frames x 150 phones
+                 dealt over the N ranks, each rank scoring and force-aligning its shard, ONE
+                 gather of the final alignments over RCCL; job utterance-frames/s, align RTF,
+                 gather_ms and a CRC of the gathered alignments that does not depend on N;
+  `batch_65536`, `real_features`, `align`, `text_align`  (N = 1 only) the same scoring step
+                 at 65,536 frames, on features of a real recording, and BASELINE configs[2]
+                 from phone strings and from text.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,7 +41,21 @@ UTT_FRAMES = 256
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, MI355X_MICROARCH.md
 N_SIMD = 1024                   # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9
-PMC_FILE = "r01_l_pmc.json"    # committed rocprofv3 --pmc measurement of this exact step
+PMC_FILE = "r02_pmc.json"      # rocprofv3 --pmc passes of this step (tools/pmc_pass.py); only
+                               # quoted when its kernel_src_sha equals this tree's
+
+
+def kernel_src_sha() -> str:
+    """Hash of everything libssw_amd.so is compiled from: ties a profile to the code it measured."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "soundswallower_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".c", ".h", ".hip", ".inc")) or name == "Makefile":
+            with open(os.path.join(csrc, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    with open(os.path.join(ROOT, "include", "ssw_amd.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(n_sen, n_feat, topn, n_cb, n_density, veclen_total, batch):
@@ -87,25 +110,140 @@ def align_config3(ssw, model, means, torch, n_utts=256, n_frames=1000, n_phones=
             "aligned": int((status == 0).sum()), "alignments_tile_their_utterances": bool(tiles)}
 
 
-def cpu_baseline(model_dir, feats, utt_off, target_s=12.0):
-    """Time the CPU oracle (scalar C restatement of the reference path) on a bounded sample."""
+# ---- CPU baseline (the only part of this file that touches oracle/) -----------------------
+def cpu_worker(model_dir, seeds, seconds):
+    """One host core (`python bench.py --cpu-worker ...`): its own oracle model, its own
+    utterances, for ~`seconds`; prints frames and seconds."""
     from oracle import oracle as O
+    from soundswallower_amd.synth import read_raw_means, synth_features
     m = O.Model(model_dir)
-    n_done, n_utt, t0 = 0, 0, time.perf_counter()
-    n_all = len(utt_off) - 1
-    while time.perf_counter() - t0 < target_s:  # cycle over the batch until ~target_s of CPU work
-        u = n_utt % n_all
-        m.ptm_score_utt(feats[utt_off[u]:utt_off[u + 1]])
-        n_done += int(utt_off[u + 1] - utt_off[u])
-        n_utt += 1
-    dt = time.perf_counter() - t0
-    return {"value": n_done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n_utt} utterance passes x {UTT_FRAMES} frames cycling over the bench batch's "
-                      f"{n_all} utterances ({n_done} frames, {dt:.1f} s, 1 thread of the CPU "
-                      f"oracle oracle/ssw_oracle.c, a scalar C port of the reference path)"}
+    means = read_raw_means(model_dir)
+    utts = [synth_features(means, UTT_FRAMES, s) for s in seeds]
+    m.ptm_score_utt(utts[0][:8])                  # page everything in before the clock starts
+    n_done, k, t0 = 0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        m.ptm_score_utt(utts[k % len(utts)])      # history reset per utterance, as the batch API
+        n_done += UTT_FRAMES
+        k += 1
+    print(json.dumps({"frames": n_done, "seconds": time.perf_counter() - t0}), flush=True)
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(model_dir, one_core_s=6.0, all_core_s=8.0):
+    """SURVEY 8(d) / BASELINE.md section 3: the reference is single-threaded, so the all-core
+    figure is N independent processes, each with its own model, each scoring its own utterances
+    of the bench workload (16 utterances x 256 frames, seeds 12345 + u, dealt over the processes
+    and cycled).  Timed on the host cores of this box with the CPU oracle (bit-identical
+    restatement of the reference path; /root/reference does not exist on the GPU box).
+    Runs BEFORE this process touches the GPU; the workers are child processes."""
+    import subprocess
+    try:
+        n_cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n_cores = os.cpu_count() or 1
+
+    def run(n_proc, seconds):
+        def seeds(p):  # a disjoint slice of the 16 utterances per process (shared beyond 16)
+            return ([12345 + u for u in range(N_UTTS) if u % n_proc == p]
+                    or [12345 + p % N_UTTS])
+        procs = [subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__), "--cpu-worker", model_dir, str(seconds)]
+            + [str(x) for x in seeds(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+            text=True) for p in range(n_proc)]
+        frames, rate, longest = 0, 0.0, 0.0
+        for p in procs:
+            so, se = p.communicate(timeout=seconds + 240)
+            if p.returncode != 0:
+                raise RuntimeError("cpu_baseline worker failed: " + se[-400:])
+            r = json.loads(so.strip().splitlines()[-1])
+            frames += r["frames"]
+            rate += r["frames"] / r["seconds"]
+            longest = max(longest, r["seconds"])
+        return frames, rate, longest
+
+    f1, r1, t1 = run(1, one_core_s)
+    fa, ra, ta = run(n_cores, all_core_s) if n_cores > 1 else (f1, r1, t1)
+    return {"value": ra, "unit": "frames/s", "cores": n_cores, "kind": "port",
+            "per_core": r1, "all_core": ra, "cpu_model": cpu_model_name(),
+            "sample": f"one process for {t1:.1f} s ({f1} frames), then {n_cores} independent "
+                      f"processes side by side for {ta:.1f} s ({fa} frames in all; the rate is "
+                      f"the sum of the processes' own rates), each with its own model, cycling "
+                      f"over its share of the bench batch's 16 utterances x {UTT_FRAMES} "
+                      f"frames (CPU oracle oracle/ssw_oracle.c, a scalar C port of the reference "
+                      f"path, bit-identical to it on the golden fixtures; gcc -O2 "
+                      f"-ffp-contract=off)"}
+
+
+# ---- the scoring step -----------------------------------------------------------------------
+class ScoreStep:
+    def __init__(self, torch, model, feats, utt_off):
+        self.model, self.utt_off = model, utt_off
+        self.n_frames = feats.shape[0]
+        self.d_feats = torch.from_numpy(feats).cuda()
+        self.d_out = torch.empty((self.n_frames, model.n_sen), dtype=torch.int16, device="cuda")
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def __call__(self):
+        self.model.score_batch_device(self.d_feats, self.n_frames, self.utt_off, self.d_out,
+                                      self.stream)
+
+    def kernel_ms(self, n):
+        """Per-kernel durations of one step from HIP events recorded on the launch stream."""
+        self.model.set_kernel_timing(True)
+        k_ms = np.zeros(2)
+        for _ in range(n):
+            self()
+            k_ms += np.array(self.model.kernel_timing())
+        self.model.set_kernel_timing(False)
+        return k_ms / n
+
+
+def spin_up(torch, step, seconds=0.5):
+    """~0.5 s of the step itself before the warm-up steps: a fresh box's GPU takes longer than
+    a few 0.1 ms steps to reach its working clock."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
+
+
+def timed_steps(torch, dist, backend, step, warmup, steps):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":   # child of cpu_baseline()
+        return cpu_worker(sys.argv[2], [int(x) for x in sys.argv[4:]], float(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -113,13 +251,13 @@ def main():
     ap.add_argument("--model", default="en-us")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-align", action="store_true",
-                    help="skip the config-3 alignment pass that fills the `align` object")
+                    help="skip the config-3 / text / config-5 alignment jobs")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the 65,536-frame and real-feature scoring lines")
     ap.add_argument("--utts", type=int, default=N_UTTS,
                     help="utterances (x256 frames) per GPU per step; the default is BASELINE.json "
                          "configs[1], 4096 frames")
     args = ap.parse_args()
-
-    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,6 +265,14 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+
+    import soundswallower_amd as ssw
+    mdir = ssw.model_dir(args.model)
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only; before any GPU call
+        cpu = cpu_baseline(mdir)
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the scoring path has no CPU fallback")
     # SSW_BENCH_BACKEND=gloo + SSW_BENCH_DEVICE=0 let several ranks share one GPU, to exercise the
@@ -144,8 +290,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    import soundswallower_amd as ssw
-    from soundswallower_amd import _lib
+    from soundswallower_amd import _lib, jobs
     from soundswallower_amd.parallel import shard_utterances
     from soundswallower_amd.synth import read_raw_means as raw_means
 
@@ -153,7 +298,6 @@ def main():
         _lib.build()
     if dist:
         dist.barrier()
-    mdir = ssw.model_dir(args.model)
     model = ssw.Model(mdir, config={"device": local_rank})
     means = raw_means(mdir)
 
@@ -164,42 +308,19 @@ def main():
     utt_off = (np.arange(len(mine) + 1) * UTT_FRAMES).astype(np.int32)
     n_frames = feats.shape[0]
 
-    d_feats = torch.from_numpy(feats).cuda()
-    d_out = torch.empty((n_frames, model.n_sen), dtype=torch.int16, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    step = ScoreStep(torch, model, feats, utt_off)
+    spin_up(torch, step)
+    elapsed = timed_steps(torch, dist, backend, step, args.warmup, args.steps)
+    k_ms = step.kernel_ms(max(1, min(args.steps, 50)))
+    flagged, pairs = model.last_stats()
 
-    def step():
-        model.score_batch_device(d_feats, n_frames, utt_off, d_out, stream)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # per-kernel durations from HIP events recorded on the same stream, same steps again
-    model.set_kernel_timing(True)
-    k_ms = np.zeros(2)
-    n_prof = max(1, min(args.steps, 50))
-    for _ in range(n_prof):
-        step()
-        k_ms += np.array(model.kernel_timing())
-    model.set_kernel_timing(False)
-    k_ms /= n_prof
+    # BASELINE configs[4] on every rank count (the multi-GPU part of the metric): collective
+    c5 = None
+    if not args.no_align and args.model == "en-us":
+        c5 = jobs.run_config5(model, means, dist, rank, world,
+                              torch.device("cuda", local_rank) if backend == "nccl" else None)
+        c5["gather_backend"] = ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) \
+            if world > 1 else "none (one rank)"
 
     if rank != 0:
         if dist:
@@ -211,18 +332,26 @@ def main():
     names = ("topn_kernel", "senone_kernel")
     total_frames = n_frames * world * args.steps
     fps = total_frames / elapsed
-    flagged, pairs = model.last_stats()
-    # roofline of the hot path = the launches of one step (top-N pass incl. its exact fix-up,
-    # senone pass); algorithmic bytes = SURVEY 8(d)'s 72,345 B/frame x frames per launch set
+    # roofline of the hot path = the launches of one step (top-N pass, senone pass);
+    # algorithmic bytes = SURVEY 8(d)'s 72,345 B/frame x frames per launch set
     path_ms = float(k_ms.sum())
     achieved = ab["path"] * n_frames / (path_ms * 1e-3) / 1e9
+    sha = kernel_src_sha()
     traffic = valu_instr = None
+    traffic_source = "not measured for this build (no profiles/%s)" % PMC_FILE
     tfile = os.path.join(ROOT, "profiles", PMC_FILE)
     if os.path.exists(tfile) and n_frames == 4096 and args.model == "en-us":
-        with open(tfile) as fh:      # PMC counters cannot be read from inside this process;
-            pmc = json.load(fh)      # committed rocprofv3 measurement of this step
-        traffic = pmc["hbm_bytes"]
-        valu_instr = pmc["valu_wave_instr_per_step"]
+        with open(tfile) as fh:      # PMC counters cannot be read from inside this process:
+            pmc = json.load(fh)      # committed rocprofv3 passes over this same command
+        if pmc.get("kernel_src_sha") == sha:
+            traffic = pmc["hbm_bytes"]
+            valu_instr = pmc["valu_wave_instr_per_step"]
+            traffic_source = (f"profiles/{PMC_FILE}: rocprofv3 --pmc passes of this command on "
+                              f"this build (kernel_src_sha {sha}); FETCH_SIZE doubled per "
+                              f"MI355X_MICROARCH.md (HBM section) for the wide streaming reads")
+        else:
+            traffic_source = (f"profiles/{PMC_FILE} was taken on kernel_src_sha "
+                              f"{pmc.get('kernel_src_sha')}, this build is {sha}: not quoted")
     per_kernel = {
         nm: {"ms": float(k_ms[i]), "algorithmic_bytes_per_frame": ab[nm],
              "achieved_GBps": ab[nm] * n_frames / (k_ms[i] * 1e-3) / 1e9,
@@ -248,9 +377,14 @@ def main():
                    "parallelism": f"utt-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "PTM path of one step: ptm_topn_frames + ptm_topn_fixup + ptm_senone",
+                     "traffic_source": traffic_source,
+                     "kernel": "PTM path of one step: ptm_topn_frames + ptm_senone",
                      "kernel_ms": path_ms, "algorithmic_bytes_per_frame": ab["path"],
-                     "note": "VALU-issue bound, not HBM bound (DESIGN.md section 5): see valu_frac"},
+                     "kernel_src_sha": sha,
+                     "note": "achieved = ALGORITHMIC (touched-bytes, SURVEY 8(d)) GB/s, not HBM "
+                             "traffic: 61.5 of the 72 KB/frame are gathers from the 2 MB mixture-"
+                             "weight table, which L2 serves; the path is VALU-issue bound "
+                             "(DESIGN.md section 5): see valu_frac"},
         "kernels": per_kernel,
         # share of the VALU issue slots the step uses if every wave64 instruction took the
         # nominal 4 cycles (SQ_INSTS_VALU from the PMC file); add/sub/mul/fma/logic issue in 2 on
@@ -259,6 +393,27 @@ def main():
                       if valu_instr else None),
         "exact_pass_share": flagged / max(pairs, 1),
     }
+    if c5 is not None:
+        out["config5"] = c5
+    if world == 1 and args.model == "en-us" and not args.no_extra:
+        # north_star says "batch >= 4096 frames": the same step at 65,536 frames per launch
+        big_utts = 256
+        bf = np.concatenate([ssw.synth_features(means, UTT_FRAMES, 12345 + u) for u in range(big_utts)])
+        boff = (np.arange(big_utts + 1) * UTT_FRAMES).astype(np.int32)
+        big = ScoreStep(torch, model, bf, boff)
+        e = timed_steps(torch, None, backend, big, 3, 20)
+        bk = big.kernel_ms(10)
+        bab = algorithmic_bytes(model.n_sen, model.n_feat, model.topn, model.n_cb,
+                                model.n_density, model.veclen_total, big.n_frames)
+        out["batch_65536"] = {
+            "workload": f"the same step at {big.n_frames} frames per launch ({big_utts} x 256)",
+            "frames_per_s": big.n_frames * 20 / e, "ms_per_step": e / 20 * 1e3,
+            "kernel_ms": float(bk.sum()),
+            "roofline_frac": bab["path"] * big.n_frames / (float(bk.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del big
+        rf = real_features(ssw, model, torch)
+        if rf is not None:
+            out["real_features"] = rf
     if not args.no_align and world == 1 and args.model == "en-us":
         out["align"] = align_config3(ssw, model, means, torch)
         # the same job from TEXT: first pass (which fillers / alternates, word frames) + the
@@ -267,11 +422,35 @@ def main():
         import bench_first_pass
         lex = ssw.Lexicon(model, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
         out["text_align"] = bench_first_pass.run(ssw, model, lex, torch)
-    if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N = 1 only
-        out["cpu_baseline"] = cpu_baseline(mdir, feats, utt_off)
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
     print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()
+
+
+def real_features(ssw, model, torch, steps=50):
+    """The scoring step on features of a real recording: the 13-dim cepstra of the reference's
+    goforward.wav (tests/golden/goforward_mfcc.npy, made by tests/golden/make_mfcc.py) through
+    ssw_feat_batch (batch CMN + deltas on the GPU), tiled to 16 utterances x 256 frames.  The
+    share of pairs that needs the exact pass depends on the data; synthetic features sit close
+    to the Gaussian means."""
+    path = os.path.join(ROOT, "tests", "golden", "goforward_mfcc.npy")
+    if not os.path.exists(path):
+        return None
+    cep = np.load(path).astype(np.float32)
+    feat = model.feat_batch(cep)                       # [n][39], one utterance
+    reps = -(-N_UTTS * UTT_FRAMES // feat.shape[0])
+    tiled = np.tile(feat, (reps, 1))[:N_UTTS * UTT_FRAMES].copy()
+    off = (np.arange(N_UTTS + 1) * UTT_FRAMES).astype(np.int32)
+    st = ScoreStep(torch, model, tiled, off)
+    e = timed_steps(torch, None, "nccl", st, 5, steps)
+    k = st.kernel_ms(10)
+    flagged, pairs = model.last_stats()
+    return {"workload": f"{len(cep)} frames of goforward.wav (cepstra -> ssw_feat_batch), tiled to "
+                        f"{N_UTTS} x {UTT_FRAMES} frames",
+            "frames_per_s": st.n_frames * steps / e, "ms_per_step": e / steps * 1e3,
+            "kernel_ms": float(k.sum()), "exact_pass_share": flagged / max(pairs, 1)}
 
 
 if __name__ == "__main__":

@@ -1,0 +1,171 @@
+"""The sharded batch-alignment job of BASELINE.json configs[4] ("config 5" in SURVEY.md 8(d)):
+N synthetic utterances x F frames x P phones, dealt over the ranks of one node; every rank
+scores its utterances (ssw_score_batch) and force-aligns them (ssw_align_batch) in chunks, and
+the final state alignments are gathered once (parallel.gather_alignments: RCCL on a GPU node,
+gloo in the CPU tests).  Used by bench.py (`config5` object of the bench line),
+tools/bench_align.py and tests/test_gpu_config5.py, so all three run the same code.
+
+Inputs follow SURVEY 8(d): features of utterance u from the LCG seed 12345 + u, its phone
+string from seed 777 + u -- the same seeds as tests/golden (config 3), so the first utterances
+of the job have committed checksums.
+"""
+from __future__ import annotations
+
+import time
+import zlib
+
+import numpy as np
+
+from .parallel import gather_alignments, shard_utterances
+from .synth import synth_alignment_task, synth_features
+
+N_UTTS, N_FRAMES, N_PHONES, CHUNK_UTTS = 2048, 1000, 150, 256
+
+
+class Config5Shard:
+    """One rank's share of the job with its inputs resident in HBM (built outside any timed
+    region): features of its utterances on the device, phone strings on the host."""
+
+    def __init__(self, model, means, rank=0, world=1, n_utts=N_UTTS, n_frames=N_FRAMES,
+                 n_phones=N_PHONES, chunk_utts=CHUNK_UTTS):
+        self.model, self.rank, self.world = model, rank, world
+        self.n_utts, self.n_frames, self.n_phones = n_utts, n_frames, n_phones
+        self.mine = shard_utterances([n_frames] * n_utts, world)[rank]
+        self.chunk_utts = max(1, min(chunk_utts, max(1, len(self.mine))))
+        sseq = model.table("sseq").reshape(-1, model.n_emit_state)
+        pssid, ptmat = model.table("phone_ssid"), model.table("phone_tmat")
+        senid, tmat = [], []
+        for u in self.mine:
+            s, t, _ = synth_alignment_task(sseq, pssid, ptmat, model.n_ciphone, n_phones, 777 + u)
+            senid.append(s)
+            tmat.append(t)
+        self.senid = (np.concatenate(senid) if senid
+                      else np.zeros((0, model.n_emit_state), np.uint16))
+        self.tmat = np.concatenate(tmat) if tmat else np.zeros(0, np.int16)
+        self.d_feats, self.d_scr = None, None
+        if self.mine:
+            # uploaded chunk by chunk: the host never holds more than one chunk of features
+            row = model.veclen_total * 4
+            self.d_feats = model.device_malloc(len(self.mine) * n_frames * row)
+            for k, u in enumerate(self.mine):
+                f = synth_features(means, n_frames, 12345 + u)
+                model._L.ssw_memcpy_h2d(self.d_feats + k * n_frames * row,
+                                        f.ctypes.data, f.nbytes)
+            self.d_scr = model.device_malloc(self.chunk_utts * n_frames * model.n_sen * 2)
+
+    def close(self):
+        for p in (self.d_feats, self.d_scr):
+            if p:
+                self.model.device_free(p)
+        self.d_feats = self.d_scr = None
+
+    def score_and_align(self):
+        """Scores and aligns the shard chunk by chunk.  Returns (states int32 [n_mine * 3P][3],
+        status int32 [n_mine], score_s, align_s)."""
+        m, F, P = self.model, self.n_frames, self.n_phones
+        n_mine = len(self.mine)
+        states = np.zeros((n_mine * P * 3, 3), np.int32)
+        status = np.zeros(n_mine, np.int32)
+        t_score = t_align = 0.0
+        row = m.veclen_total * 4
+        for c0 in range(0, n_mine, self.chunk_utts):
+            c1 = min(n_mine, c0 + self.chunk_utts)
+            n = c1 - c0
+            frame_off = (np.arange(n + 1) * F).astype(np.int32)
+            phone_off = (np.arange(n + 1) * P).astype(np.int32)
+            t0 = time.perf_counter()
+            m.score_batch_device(self.d_feats + c0 * F * row, n * F, frame_off, self.d_scr)
+            m._L.ssw_device_synchronize()
+            t1 = time.perf_counter()
+            st, stat = m.align_batch(self.d_scr, frame_off, phone_off,
+                                     self.senid[c0 * P:c1 * P], self.tmat[c0 * P:c1 * P])
+            t2 = time.perf_counter()
+            states[c0 * P * 3:c1 * P * 3] = st
+            status[c0:c1] = stat
+            t_score += t1 - t0
+            t_align += t2 - t1
+        return states, status, t_score, t_align
+
+    def run(self, dist=None, device=None):
+        """One pass of the whole job on this rank: score + align its shard, then the single
+        gather.  Returns a dict; `per_utt` (list indexed by global utterance id) on every rank."""
+        P = self.n_phones
+        t0 = time.perf_counter()
+        states, status, t_score, t_align = self.score_and_align()
+        t1 = time.perf_counter()
+        local = [states[k * P * 3:(k + 1) * P * 3] for k in range(len(self.mine))]
+        if dist is not None and self.world > 1:
+            per_utt = gather_alignments(local, [P * 3] * self.n_utts, self.world, self.rank,
+                                        n_frames_per_utt=[self.n_frames] * self.n_utts,
+                                        device=device)
+        else:
+            per_utt = [None] * self.n_utts
+            for k, u in enumerate(self.mine):
+                per_utt[u] = local[k]
+        t2 = time.perf_counter()
+        tiles = all(int(local[k][:, 1].sum()) == self.n_frames
+                    for k in range(len(self.mine)) if status[k] == 0)
+        return {"per_utt": per_utt, "status": status, "score_s": t_score, "align_s": t_align,
+                "gather_s": t2 - t1, "wall_s": t2 - t0, "tiles": bool(tiles),
+                "aligned": int((status == 0).sum())}
+
+
+def alignment_crc(per_utt) -> int:
+    """CRC-32 of the state alignments in global utterance order: the same value whatever the
+    number of ranks the job ran on."""
+    c = 0
+    for a in per_utt:
+        c = zlib.crc32(np.ascontiguousarray(a, np.int32).tobytes(), c)
+    return c & 0xFFFFFFFF
+
+
+def run_config5(model, means, dist=None, rank=0, world=1, device=None, reps=2, n_utts=N_UTTS,
+                n_frames=N_FRAMES, n_phones=N_PHONES, chunk_utts=CHUNK_UTTS, keep=4):
+    """The whole job, `reps` times, best wall (max over ranks) reported.  Every rank must call
+    it.  Returns on every rank a dict of job-level numbers (rank 0's are the ones to print);
+    `first_states_crc` = CRC-32 of each of the first `keep` utterances' state alignments,
+    comparable with tests/golden/synthetic_oracle.json config3_align."""
+    shard = Config5Shard(model, means, rank, world, n_utts, n_frames, n_phones, chunk_utts)
+    best = None
+    try:
+        for _ in range(reps):
+            if dist is not None and world > 1:
+                dist.barrier()
+            r = shard.run(dist, device)
+            wall, ok, tiles = r["wall_s"], r["aligned"], int(r["tiles"])
+            if dist is not None and world > 1:
+                import torch
+                dev = device if device is not None else "cpu"
+                tmax = torch.tensor([wall, r["score_s"], r["align_s"], r["gather_s"]],
+                                    dtype=torch.float64, device=dev)
+                tsum = torch.tensor([float(ok), float(tiles)], dtype=torch.float64, device=dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+                wall, score_s, align_s, gather_s = (float(x) for x in tmax.cpu())
+                ok, tiles = int(tsum[0].item()), int(tsum[1].item())
+            else:
+                score_s, align_s, gather_s = r["score_s"], r["align_s"], r["gather_s"]
+            if best is None or wall < best["wall_s"]:
+                best = {"wall_s": wall, "score_s": score_s, "align_s": align_s,
+                        "gather_s": gather_s, "aligned": ok, "tiles": tiles == world,
+                        "per_utt": r["per_utt"]}
+    finally:
+        shard.close()
+    job_frames = n_utts * n_frames
+    per_utt = best.pop("per_utt")
+    complete = all(a is not None for a in per_utt)
+    return {
+        "workload": f"{n_utts} utterances x {n_frames} frames x {n_phones} phones, en-us, dealt "
+                    f"over {world} rank(s) in chunks of {min(chunk_utts, n_utts)} utterances: PTM "
+                    f"scoring + forced alignment per rank, one gather of the state alignments "
+                    f"(BASELINE configs[4])",
+        "n_ranks": world, "n_utts": n_utts,
+        "wall_ms": best["wall_s"] * 1e3, "score_ms": best["score_s"] * 1e3,
+        "align_ms": best["align_s"] * 1e3, "gather_ms": best["gather_s"] * 1e3,
+        "job_utt_frames_per_s": job_frames / best["wall_s"],
+        "align_rtf": best["wall_s"] / (job_frames / 100.0),
+        "aligned": best["aligned"], "alignments_tile_their_utterances": bool(best["tiles"]),
+        "gathered_all": bool(complete),
+        "alignment_crc32": alignment_crc(per_utt) if complete else None,
+        "first_states_crc": [alignment_crc([a]) for a in per_utt[:keep]] if complete else None,
+    }

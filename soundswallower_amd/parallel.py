@@ -21,24 +21,34 @@ def shard_utterances(n_frames_per_utt, world_size: int):
     return shards
 
 
-def gather_alignments(local_states, local_utts, n_states_per_utt, world_size: int, rank: int,
-                      device=None):
+def gather_alignments(local_states, n_states_per_utt, world_size: int, rank: int, *,
+                      n_frames_per_utt=None, plan=None, device=None):
     """All-gather the per-utterance state alignments.
 
-    local_states: list of int32 arrays [n_states_u][3] for this rank's utterances (in the order
-    of local_utts); n_states_per_utt: state count of EVERY utterance (known to all ranks, it is
-    a function of the transcripts).  Returns a list indexed by global utterance id.
-    One padded all_gather: ranks have different totals, so each sends max_total rows."""
+    local_states: list of int32 arrays [n_states_u][3] for this rank's utterances, in the order
+    of its shard; n_states_per_utt: state count of EVERY utterance (known to all ranks, it is a
+    function of the transcripts); the shard plan is either given (`plan`, world_size lists of
+    utterance ids) or recomputed from `n_frames_per_utt` -- shard_utterances is a pure function
+    of the lengths, so no exchange is needed to agree on it.  Returns a list indexed by global
+    utterance id.  One padded all_gather: ranks have different totals, so each sends max_total
+    rows."""
     import torch
     import torch.distributed as dist
 
-    shards_sizes = [0] * world_size
-    plan = shard_utterances_by_list(local_utts, world_size, rank)
+    if plan is None:
+        if n_frames_per_utt is None:
+            raise ValueError("gather_alignments needs the shard plan or the utterance lengths")
+        plan = shard_utterances(n_frames_per_utt, world_size)
+    if len(local_states) != len(plan[rank]):
+        raise ValueError(f"rank {rank} holds {len(local_states)} alignments, its shard has "
+                         f"{len(plan[rank])} utterances")
     totals = [sum(int(n_states_per_utt[u]) for u in utts) for utts in plan]
     max_total = max(totals) if totals else 0
     flat = np.zeros((max_total, 3), np.int32)
     if local_states:
         cat = np.concatenate([np.asarray(s, np.int32).reshape(-1, 3) for s in local_states])
+        if cat.shape[0] != totals[rank]:
+            raise ValueError(f"rank {rank}: {cat.shape[0]} state rows, the plan says {totals[rank]}")
         flat[:cat.shape[0]] = cat
     t = torch.from_numpy(flat)
     if device is not None:
@@ -53,17 +63,7 @@ def gather_alignments(local_states, local_utts, n_states_per_utt, world_size: in
             n = int(n_states_per_utt[u])
             out[u] = rows[pos:pos + n].copy()
             pos += n
-    del shards_sizes
     return [out[u] for u in sorted(out)]
-
-
-def shard_utterances_by_list(local_utts, world_size, rank):
-    """Exchange every rank's utterance list (tiny) so all ranks know the full plan."""
-    import torch.distributed as dist
-
-    plan = [None] * world_size
-    dist.all_gather_object(plan, [int(u) for u in local_utts])
-    return plan
 
 
 def gather_text_alignments(local, local_utts, world_size: int, rank: int, device=None):

@@ -44,7 +44,7 @@ def _worker(rank, world, port, n_states, q):
         n = n_states[u]
         local.append(np.stack([np.arange(n) * (u + 1), np.full(n, u + 1), -np.arange(n) - u], 1)
                      .astype(np.int32))
-    full = gather_alignments(local, mine, n_states, world, rank)
+    full = gather_alignments(local, n_states, world, rank, n_frames_per_utt=lens)
     if rank == 0:
         q.put([a.tolist() for a in full])
     dist.barrier()
@@ -121,3 +121,62 @@ def test_gather_text_alignments_world2():
             assert got[u] is None
         else:
             assert {k: v.tolist() for k, v in want.items()} == got[u]
+
+
+# ---- a scaled-down config-5 job with real per-rank compute (the CPU oracle stands in for the
+# GPU kernels; sharding plan, gather and CRC are the product code of soundswallower_amd.jobs) ----
+_JOB = dict(n_utts=7, n_frames=48, n_phones=6)
+
+
+def _oracle_job_states(utts):
+    from oracle import oracle as O
+    from soundswallower_amd.synth import read_raw_means, synth_alignment_task, synth_features
+    mdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                        "soundswallower_amd", "model", "en-us")
+    om = O.Model(mdir)
+    means = read_raw_means(mdir)
+    out = []
+    for u in utts:
+        scr = om.ptm_score_utt(synth_features(means, _JOB["n_frames"], 12345 + u))
+        senid, tmat, _ = synth_alignment_task(om.sseq, om.phone_ssid, om.phone_tmat, om.n_ciphone,
+                                              _JOB["n_phones"], 777 + u)
+        rv, st, _ = om.state_align(scr, senid, tmat)
+        assert rv == 0
+        out.append(np.asarray(st, np.int32))
+    return out
+
+
+def _job_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from soundswallower_amd.jobs import alignment_crc
+    from soundswallower_amd.parallel import gather_alignments
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lens = [_JOB["n_frames"]] * _JOB["n_utts"]
+    mine = shard_utterances(lens, world)[rank]
+    local = _oracle_job_states(mine)
+    full = gather_alignments(local, [3 * _JOB["n_phones"]] * _JOB["n_utts"], world, rank,
+                             n_frames_per_utt=lens)
+    if rank == 0:
+        q.put((alignment_crc(full), [int(a[:, 1].sum()) for a in full]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_sharded_alignment_job_crc_does_not_depend_on_rank_count():
+    from soundswallower_amd.jobs import alignment_crc
+    want = alignment_crc(_oracle_job_states(range(_JOB["n_utts"])))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_job_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    crc, durs = q.get(timeout=150)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert crc == want
+    assert durs == [_JOB["n_frames"]] * _JOB["n_utts"]   # every alignment tiles its utterance
