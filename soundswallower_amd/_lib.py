@@ -10,7 +10,9 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libssw_amd.so")
+# SSW_AMD_LIB: load another build of the same library (the instrumented ones of
+# `make -C soundswallower_amd/csrc timeline`); never set in tests or bench runs
+LIB_PATH = os.environ.get("SSW_AMD_LIB") or os.path.join(_HERE, "libssw_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "ssw_amd.h")
 
@@ -53,6 +55,8 @@ def build(force: bool = False) -> str:
     """Compile libssw_amd.so for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
             if f.endswith((".c", ".hip", ".h", ".inc"))] + [HEADER]
+    if os.environ.get("SSW_AMD_LIB"):
+        return LIB_PATH
     stale = (not os.path.exists(LIB_PATH)
              or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))
     if force or stale:

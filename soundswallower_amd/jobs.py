@@ -124,7 +124,7 @@ def run_config5(model, means, dist=None, rank=0, world=1, device=None, reps=2, n
     """The whole job, `reps` times, best wall (max over ranks) reported.  Every rank must call
     it.  Returns on every rank a dict of job-level numbers (rank 0's are the ones to print);
     `first_states_crc` = CRC-32 of each of the first `keep` utterances' state alignments,
-    comparable with tests/golden/synthetic_oracle.json config3_align."""
+    comparable with the committed config-3 checksums under tests/golden/."""
     shard = Config5Shard(model, means, rank, world, n_utts, n_frames, n_phones, chunk_utts)
     best = None
     try:

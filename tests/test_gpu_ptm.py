@@ -200,3 +200,67 @@ def test_ptm_edge_shapes(gpu_en, orc_en, means_en):
         gpu_en.score_batch(feats, np.array([0, 41], np.int32))      # offsets past the batch
     with pytest.raises(Exception):
         gpu_en.score_batch(feats, np.array([0, 30, 20, 40], np.int32))  # not ascending
+
+
+def _unprovable_pairs(orc, means, x):
+    """[n][n_cb][n_feat] bool: pairs whose top-N list may depend on the carried history -- the
+    four best truncated densities are not four distinct ints above every other density's
+    (DESIGN.md section 4).  Reference arithmetic in numpy float32 (one rounding per operation)."""
+    n_cb, n_feat, n_den, vl = means.shape
+    mean = orc.mean.reshape(means.shape)
+    var = orc.var.reshape(means.shape)
+    det = orc.det.reshape(n_cb, n_feat, n_den)
+    x = np.ascontiguousarray(x, np.float32).reshape(len(x), 1, n_feat, 1, vl)
+    d = np.broadcast_to(det, (x.shape[0],) + det.shape).astype(np.float32).copy()
+    for j in range(vl):
+        diff = x[..., j] - mean[None, ..., j]
+        sq = diff * diff
+        d = d - sq * var[None, ..., j]
+    iv = np.trunc(np.maximum(d, np.float32(-2147483648.0))).astype(np.int64)
+    top = -np.sort(-iv, axis=-1)[..., :5]
+    distinct = (top[..., 0] > top[..., 1]) & (top[..., 1] > top[..., 2]) \
+        & (top[..., 2] > top[..., 3]) & (top[..., 3] > top[..., 4])
+    return ~distinct
+
+
+@pytest.mark.parametrize("total", [2600, 900])
+def test_ptm_runs_of_history_dependent_frames_across_tiles(gpu_en, orc_en, means_en, total):
+    """The exact in-wave pass of the frames kernel under the worst inputs for it: long runs of
+    IDENTICAL frames (digital silence does this to real audio) whose top-N lists tie, so that
+    every frame of a run depends on its predecessor.  Runs longer than a tile (128 frames at 2
+    frames per lane, 64 at 1) make waves re-derive the order their tile starts from by walking
+    back over frames they do not own; runs across the boundary between a lane's first and second
+    frame, runs that start mid-tile, and an utterance boundary inside a run (reset history) are
+    all here.  `total` selects the kernel variant: 2 frames per lane from ~2100 frames up."""
+    rng = np.random.default_rng(42 + total)
+    cand = synth_features(means_en, 600, 31337)
+    cand = (np.round(cand * 8.0) / 8.0).astype(np.float32)     # coarse grid: more ties
+    bad = _unprovable_pairs(orc_en, means_en, cand)
+    idx = np.argsort(-bad.reshape(len(cand), -1).sum(axis=1))[:6]
+    assert bad[idx[0]].any(), "no candidate frame with a history-dependent pair"
+    ties = cand[idx]
+    filler = synth_features(means_en, 64, 999)
+    parts, lens = [], []
+    pos = 0
+    runs = [3, 331, 17, 140, 1, 129, 65, 64, 200]
+    k = 0
+    while pos < total:
+        n = runs[k % len(runs)]
+        if k % 2 == 0:
+            blk = filler[rng.integers(0, len(filler), n)]
+        else:
+            blk = np.repeat(ties[(k // 2) % len(ties)][None], n, axis=0)
+        parts.append(blk)
+        pos += n
+        k += 1
+    feats = np.ascontiguousarray(np.concatenate(parts)[:total], np.float32)
+    # utterance boundaries: one inside the first long run, one at a tile edge, one ragged
+    off = np.array([0, 150, 384, 385, total], np.int32)
+    got = gpu_en.score_batch(feats, off)
+    flagged, pairs = gpu_en.last_stats()
+    gcw, _ = gpu_en.last_topn(len(feats))
+    ref, rcw, _ = _oracle_batch(orc_en, feats, off)
+    assert pairs == total * 126
+    assert flagged >= 300, "the runs should put many pairs through the exact pass"
+    assert np.array_equal(gcw.astype(np.int32), rcw)
+    assert np.array_equal(got, ref)

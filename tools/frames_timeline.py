@@ -1,6 +1,9 @@
+"""Per-wave phase time stamps of ptm_topn_frames_kernel (development aid).
+Build the instrumented library first:  make -C soundswallower_amd/csrc timeline
+then run this on the GPU box."""
 import os, sys, shutil, numpy as np
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
-shutil.copy(os.path.join(root, "gpurun_tl/libssw_amd.so"), os.path.join(root, "soundswallower_amd/libssw_amd.so"))
+os.environ["SSW_AMD_LIB"] = os.path.join(root, "gpurun_tl/libssw_amd_SSW_TIMELINE.so")
 os.environ["SSW_TIMELINE_OUT"] = "/tmp/tl.bin"
 sys.path.insert(0, root)
 import torch
@@ -13,6 +16,8 @@ for i in range(5):
     out = m.score_batch_host(feats, off) if hasattr(m, "score_batch_host") else m.score_batch(feats, off)
 tl = np.fromfile("/tmp/tl.bin", dtype=np.uint64).reshape(-1, 6)
 tl = tl[tl[:, 0] != 0]
+if len(sys.argv) > 1:
+    np.save(sys.argv[1], tl)
 xcc_all = tl[:, 5].astype(np.int64) & 0xf
 hw_all = tl[:, 4].astype(np.int64)
 grp = xcc_all * 100000 + ((hw_all >> 13) & 7) * 1000 + ((hw_all >> 8) & 15)

@@ -1,10 +1,10 @@
 """Per-wave phase time stamps of ptm_senone_kernel (development aid).
 
-Build the instrumented library first:  make -C soundswallower_amd/csrc timeline TLFLAGS=-DSSW_TIMELINE_SEN -B
-(with -USSW_TIMELINE semantics: pass TLDEF=SSW_TIMELINE_SEN), then run this on the GPU box."""
+Build the instrumented library first:  make -C soundswallower_amd/csrc timeline TLDEF=SSW_TIMELINE_SEN
+then run this on the GPU box."""
 import os, sys, shutil, numpy as np
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
-shutil.copy(os.path.join(root, "gpurun_tl/libssw_amd.so"), os.path.join(root, "soundswallower_amd/libssw_amd.so"))
+os.environ["SSW_AMD_LIB"] = os.path.join(root, "gpurun_tl/libssw_amd_SSW_TIMELINE_SEN.so")
 os.environ["SSW_TIMELINE_OUT"] = "/tmp/tl.bin"
 sys.path.insert(0, root)
 from soundswallower_amd import api, synth
