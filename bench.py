@@ -317,10 +317,32 @@ def main():
     # BASELINE configs[4] on every rank count (the multi-GPU part of the metric): collective
     c5 = None
     if not args.no_align and args.model == "en-us":
+        # the gather goes through the library's C entry point (ssw_gather_alignments over its own
+        # RCCL communicator) when the ranks are on GPUs of their own; SSW_GATHER=torch, a failed
+        # communicator set-up, or the gloo shared-GPU test mode use torch.distributed instead
+        comm, how = None, "none (one rank)"
+        if world > 1:
+            how = "rccl (torch.distributed nccl)" if backend == "nccl" else backend
+            if backend == "nccl" and os.environ.get("SSW_GATHER", "c") == "c":
+                from soundswallower_amd.parallel import RcclComm
+                try:
+                    comm = RcclComm(dist, world, rank, local_rank)
+                    how = "rccl (ssw_gather_alignments, C ABI)"
+                except Exception as e:      # noqa: BLE001 -- reported in the line
+                    how += f" [C communicator unavailable: {e}]"
+            ok = torch.tensor([1 if comm is not None else 0],
+                              device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # all ranks take the same route
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
+                how = "rccl (torch.distributed nccl) [C communicator missing on another rank]"
         c5 = jobs.run_config5(model, means, dist, rank, world,
-                              torch.device("cuda", local_rank) if backend == "nccl" else None)
-        c5["gather_backend"] = ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) \
-            if world > 1 else "none (one rank)"
+                              torch.device("cuda", local_rank) if backend == "nccl" else None,
+                              comm=comm)
+        c5["gather_backend"] = how
+        if comm is not None:
+            comm.close()
 
     if rank != 0:
         if dist:

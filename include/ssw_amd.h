@@ -264,7 +264,9 @@ typedef struct ssw_word_seg_s {
  * frames utt_off[u] .. utt_off[u+1]); words: the texts, utterance u = words[word_off[u] ..
  * word_off[u+1]).  seg: [n_utts][max_seg]; n_seg[u] = segments written, or -1 when the
  * grammar's final state is not reached in the last frame that has word exits ("Final result
- * does not match the grammar", src/fsg_search.c:913-916) or max_seg is too small.
+ * does not match the grammar", src/fsg_search.c:913-916), or -(2 + k) when the search succeeded
+ * but its k segments do not fit max_seg (call again with max_seg >= k; ssw_forced_align_batch
+ * and ssw_align_text_batch do that themselves).
  * cfg NULL = defaults.  Returns 0, or -1 (unknown word, graph too large, no device).
  * Synchronous on `stream`. */
 int ssw_first_pass_batch(ssw_model_t *m, const ssw_dict_t *d, const ssw_first_pass_config_t *cfg,
@@ -380,6 +382,33 @@ int32_t ssw_alignment_json(const ssw_model_t *m, const char *hyp, int32_t hyp_lo
 int ssw_feat_batch(ssw_model_t *m, const float *d_cep, int32_t n_frames,
                    const int32_t *utt_off, int32_t n_utts, int32_t ncep, float *d_out,
                    void *stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Multi-GPU (NEW: the reference is single-process).  The path shards by utterance -- one   */
+/* process per GPU, the model replicated, no exchange while scoring and aligning -- and the  */
+/* only collective is ONE gather of the final alignment entries over RCCL (xGMI inside a      */
+/* node).  What is gathered is the state level of alignment_t (include/soundswallower/         */
+/* alignment.h:60-109) as ssw_align_batch returns it; alignment_propagate then runs wherever   */
+/* the word / phone levels are wanted.  RCCL is bound at run time, so single-GPU hosts do not  */
+/* need it installed.                                                                          */
+/* ------------------------------------------------------------------------------------ */
+typedef struct ssw_comm_s ssw_comm_t;
+#define SSW_COMM_ID_BYTES 128
+/* ncclGetUniqueId: called by ONE rank, which hands the 128 bytes to the others by whatever
+ * channel the host has (MPI, a file, torch.distributed ...) */
+int ssw_comm_unique_id(char id[SSW_COMM_ID_BYTES]);
+/* ncclCommInitRank on `device`; collective over the n_ranks callers */
+ssw_comm_t *ssw_comm_init(const char id[SSW_COMM_ID_BYTES], int32_t n_ranks, int32_t rank,
+                          int32_t device);
+/* wrap a communicator the host already has (an ncclComm_t); not destroyed by ssw_comm_free */
+ssw_comm_t *ssw_comm_from_nccl(void *nccl_comm, int32_t n_ranks, int32_t rank, int32_t device);
+void ssw_comm_free(ssw_comm_t *c);
+/* Collective.  local: this rank's n_local entries (the state entries of its utterances, in its
+ * shard's order); counts [n_ranks]: entries of every rank -- known to all of them, being a
+ * function of the transcripts and the shard plan; out [sum(counts)]: all entries in rank order,
+ * on every rank (host memory).  One padded ncclAllGather; synchronous on `stream`. */
+int ssw_gather_alignments(ssw_comm_t *c, const ssw_align_entry_t *local, int32_t n_local,
+                          const int32_t *counts, ssw_align_entry_t *out, void *stream);
 
 /* device-memory helpers so a C caller needs no HIP headers */
 void *ssw_device_malloc(size_t nbytes);

@@ -165,6 +165,14 @@ def lib() -> C.CDLL:
     L.ssw_alignment_populate.restype = i32
     L.ssw_alignment_populate.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.ssw_feat_batch.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
+    L.ssw_comm_unique_id.argtypes = [C.c_char_p]
+    L.ssw_comm_init.restype = vp
+    L.ssw_comm_init.argtypes = [C.c_char_p, i32, i32, i32]
+    L.ssw_comm_from_nccl.restype = vp
+    L.ssw_comm_from_nccl.argtypes = [vp, i32, i32, i32]
+    L.ssw_comm_free.argtypes = [vp]
+    L.ssw_comm_free.restype = None
+    L.ssw_gather_alignments.argtypes = [vp, vp, i32, vp, vp, vp]
     L.ssw_device_malloc.restype = vp
     L.ssw_device_malloc.argtypes = [sz]
     L.ssw_device_free.argtypes = [vp]

@@ -443,6 +443,8 @@ class Lexicon:
         n_seg, seg = self.first_pass_raw(d_senscr, utt_off, texts, cfg, max_seg, stream)
         out = []
         for u in range(len(n_seg)):
+            if n_seg[u] <= -2:
+                raise SswError(f"first_pass: utterance {u} needs max_seg >= {-n_seg[u] - 2}")
             if n_seg[u] < 0:
                 out.append(None)
             else:

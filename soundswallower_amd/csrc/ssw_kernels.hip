@@ -24,7 +24,8 @@
  *   ssw_k5_firstpass.inc first_pass_kernel (fsg_search start/step/finish over the linear
  *                        grammar's phone trees, src/fsg_search.c:665-925)
  *   ssw_host_*.inc       device model and loaders' upload, batched scoring, alignment, the
- *                        mgau_t / search-module shaped objects, features, device-memory helpers
+ *                        mgau_t / search-module shaped objects, features, device-memory helpers,
+ *                        the RCCL gather of final alignments (ssw_host_comm.inc)
  */
 #pragma clang fp contract(off)
 
@@ -73,3 +74,4 @@ namespace {
 #include "ssw_host_feat.inc"
 #include "ssw_host_firstpass.inc"
 #include "ssw_host_devmem.inc"
+#include "ssw_host_comm.inc"

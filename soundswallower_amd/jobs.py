@@ -86,7 +86,7 @@ class Config5Shard:
             t_align += t2 - t1
         return states, status, t_score, t_align
 
-    def run(self, dist=None, device=None):
+    def run(self, dist=None, device=None, comm=None):
         """One pass of the whole job on this rank: score + align its shard, then the single
         gather.  Returns a dict; `per_utt` (list indexed by global utterance id) on every rank."""
         P = self.n_phones
@@ -97,7 +97,7 @@ class Config5Shard:
         if dist is not None and self.world > 1:
             per_utt = gather_alignments(local, [P * 3] * self.n_utts, self.world, self.rank,
                                         n_frames_per_utt=[self.n_frames] * self.n_utts,
-                                        device=device)
+                                        device=device, comm=comm)
         else:
             per_utt = [None] * self.n_utts
             for k, u in enumerate(self.mine):
@@ -120,7 +120,7 @@ def alignment_crc(per_utt) -> int:
 
 
 def run_config5(model, means, dist=None, rank=0, world=1, device=None, reps=2, n_utts=N_UTTS,
-                n_frames=N_FRAMES, n_phones=N_PHONES, chunk_utts=CHUNK_UTTS, keep=4):
+                n_frames=N_FRAMES, n_phones=N_PHONES, chunk_utts=CHUNK_UTTS, keep=4, comm=None):
     """The whole job, `reps` times, best wall (max over ranks) reported.  Every rank must call
     it.  Returns on every rank a dict of job-level numbers (rank 0's are the ones to print);
     `first_states_crc` = CRC-32 of each of the first `keep` utterances' state alignments,
@@ -131,7 +131,7 @@ def run_config5(model, means, dist=None, rank=0, world=1, device=None, reps=2, n
         for _ in range(reps):
             if dist is not None and world > 1:
                 dist.barrier()
-            r = shard.run(dist, device)
+            r = shard.run(dist, device, comm)
             wall, ok, tiles = r["wall_s"], r["aligned"], int(r["tiles"])
             if dist is not None and world > 1:
                 import torch

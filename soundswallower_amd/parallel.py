@@ -21,8 +21,55 @@ def shard_utterances(n_frames_per_utt, world_size: int):
     return shards
 
 
+class RcclComm:
+    """ssw_comm_t: the library's own RCCL communicator (include/ssw_amd.h, "Multi-GPU"), for the
+    one gather of the path.  Rank 0 draws the unique id (ssw_comm_unique_id) and the 128 bytes
+    travel over the process group the host already has (torch.distributed here, MPI or a file
+    for a C host); every rank then joins with ssw_comm_init."""
+
+    def __init__(self, dist, world_size: int, rank: int, device_index: int):
+        import ctypes as C
+
+        import torch
+
+        from . import _lib
+        self._L = _lib.lib()
+        buf = C.create_string_buffer(128)
+        if rank == 0 and self._L.ssw_comm_unique_id(buf) < 0:
+            raise RuntimeError("ssw_comm_unique_id: " + _lib.last_error())
+        t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if world_size > 1:
+            backend = dist.get_backend()
+            t = t.to(torch.device("cuda", device_index)) if backend == "nccl" else t
+            dist.broadcast(t, src=0)
+        idb = bytes(t.cpu().numpy().tobytes())
+        self._c = self._L.ssw_comm_init(idb, world_size, rank, device_index)
+        if not self._c:
+            raise RuntimeError("ssw_comm_init: " + _lib.last_error())
+        self.world_size, self.rank = world_size, rank
+
+    def gather(self, local: np.ndarray, counts) -> np.ndarray:
+        """local int32 [n_local][3]; counts: entries of every rank.  Returns [sum(counts)][3]."""
+        from . import _lib
+        local = np.ascontiguousarray(local, np.int32).reshape(-1, 3)
+        counts = np.ascontiguousarray(counts, np.int32)
+        out = np.zeros((int(counts.sum()), 3), np.int32)
+        rv = self._L.ssw_gather_alignments(self._c, local.ctypes.data, len(local),
+                                           counts.ctypes.data, out.ctypes.data, None)
+        if rv < 0:
+            raise RuntimeError("ssw_gather_alignments: " + _lib.last_error())
+        return out
+
+    def close(self):
+        if getattr(self, "_c", None):
+            self._L.ssw_comm_free(self._c)
+            self._c = None
+
+    __del__ = close
+
+
 def gather_alignments(local_states, n_states_per_utt, world_size: int, rank: int, *,
-                      n_frames_per_utt=None, plan=None, device=None):
+                      n_frames_per_utt=None, plan=None, device=None, comm=None):
     """All-gather the per-utterance state alignments.
 
     local_states: list of int32 arrays [n_states_u][3] for this rank's utterances, in the order
@@ -31,10 +78,8 @@ def gather_alignments(local_states, n_states_per_utt, world_size: int, rank: int
     utterance ids) or recomputed from `n_frames_per_utt` -- shard_utterances is a pure function
     of the lengths, so no exchange is needed to agree on it.  Returns a list indexed by global
     utterance id.  One padded all_gather: ranks have different totals, so each sends max_total
-    rows."""
-    import torch
-    import torch.distributed as dist
-
+    rows.  With `comm` (an RcclComm) the exchange is the library's C entry point
+    ssw_gather_alignments -- what a C host calls -- instead of torch.distributed."""
     if plan is None:
         if n_frames_per_utt is None:
             raise ValueError("gather_alignments needs the shard plan or the utterance lengths")
@@ -43,6 +88,22 @@ def gather_alignments(local_states, n_states_per_utt, world_size: int, rank: int
         raise ValueError(f"rank {rank} holds {len(local_states)} alignments, its shard has "
                          f"{len(plan[rank])} utterances")
     totals = [sum(int(n_states_per_utt[u]) for u in utts) for utts in plan]
+    if comm is not None:
+        cat = (np.concatenate([np.asarray(s, np.int32).reshape(-1, 3) for s in local_states])
+               if local_states else np.zeros((0, 3), np.int32))
+        if cat.shape[0] != totals[rank]:
+            raise ValueError(f"rank {rank}: {cat.shape[0]} state rows, the plan says {totals[rank]}")
+        rows = comm.gather(cat, totals)
+        out, pos = {}, 0
+        for r in range(world_size):
+            for u in plan[r]:
+                n = int(n_states_per_utt[u])
+                out[u] = rows[pos:pos + n].copy()
+                pos += n
+        return [out[u] for u in sorted(out)]
+    import torch
+    import torch.distributed as dist
+
     max_total = max(totals) if totals else 0
     flat = np.zeros((max_total, 3), np.int32)
     if local_states:

@@ -69,3 +69,23 @@ def test_config5_two_ranks_through_bench_py(one_gpu_job):
     assert c5["alignment_crc32"] == one_gpu_job["alignment_crc32"]
     assert c5["first_states_crc"] == one_gpu_job["first_states_crc"]
     assert c5["gather_ms"] > 0
+
+
+def test_c_gather_entry_point_one_rank(gpu_en):
+    """ssw_comm_unique_id / ssw_comm_init / ssw_gather_alignments (the multi-GPU entry points a C
+    host calls) on a one-rank RCCL communicator: the gather returns the local entries.  More
+    ranks need a GPU each (RCCL refuses two ranks on one device); the sharded job over two ranks
+    is covered through gloo above, and rank-count independence of the exchange by the CPU test."""
+    import numpy as np
+    from soundswallower_amd.parallel import RcclComm, gather_alignments
+    comm = RcclComm(None, 1, 0, 0)
+    try:
+        rng = np.random.default_rng(3)
+        local = [rng.integers(-1000, 1000, (n, 3)).astype(np.int32) for n in (9, 3, 450)]
+        got = gather_alignments(local, [9, 3, 450], 1, 0, n_frames_per_utt=[5, 4, 3], comm=comm)
+        # plan for one rank = longest first: utterances 0, 1, 2 in that order
+        assert all(np.array_equal(a, b) for a, b in zip(got, local))
+        again = comm.gather(np.concatenate(local), [462])
+        assert np.array_equal(again, np.concatenate(local))
+    finally:
+        comm.close()

@@ -383,3 +383,70 @@ def test_french_recording_from_cepstra(oracle_mod, gpu_fr):
     assert line.startswith('{"b":0.000,"d":2.400,"p":1.000,"t":"avance de dix mètres","w":[{"b":0.000,"d":0.320,')
     assert '"t":"de(2)"' in line and '"t":"mètres(4)"' in line
     aset.free()
+
+
+def test_many_filler_segments_for_a_short_text(oracle_mod, gpu_en, orc_en):
+    """One word over audio full of alternating fillers: the backtrace has far more segments than
+    a buffer sized from the word count (8 x words + 32).  ssw_first_pass_batch then reports how
+    much room it needs (-(2 + k), not the 'no path' code -1), ssw_forced_align_batch searches
+    again with that room, and the result is the reference's segmentation -- alone in its batch
+    or next to a long text (the same utterance must not succeed in one batch and
+    fail in another)."""
+    lex = _lex(gpu_en, "en-us")
+    F, olex = _olex(oracle_mod, orc_en, "en-us")
+    words = ["go"]
+    nodes, _ = lex.first_pass_graph(words)
+    name = [lex.word(int(n["wid"])) if (n["flags"] & 2) else None for n in nodes]
+
+    def filler(state, w):
+        for i, n in enumerate(nodes):
+            if (n["flags"] & 2) and (n["flags"] & 1) and n["state"] == state and name[i] == w:
+                return i
+        raise AssertionError((state, w))
+
+    kids = {}
+    for i, n in enumerate(nodes):
+        if n["parent"] >= 0:
+            kids.setdefault(int(n["parent"]), []).append(i)
+    path = []
+    for k in range(90):
+        path.append(filler(0, "<sil>" if k % 2 == 0 else "[NOISE]"))
+    i = [i for i, n in enumerate(nodes) if (n["flags"] & 1) and n["state"] == 0
+         and name[i] is None or (n["flags"] & 1) and n["state"] == 0 and name[i] == "go"][0]
+    while True:
+        path.append(i)
+        if nodes[i]["flags"] & 2:
+            break
+        i = kids[i][0]
+    for k in range(90):
+        path.append(filler(1, "[NOISE]" if k % 2 == 0 else "<sil>"))
+    rng = np.random.default_rng(11)
+    rows = []
+    for i in path:
+        for sen in nodes[i]["senid"]:
+            for _ in range(2):
+                row = rng.integers(150, 400, gpu_en.n_sen).astype(np.int16)
+                row[sen] = rng.integers(0, 20)
+                rows.append(row)
+    scr = np.stack(rows)
+    want = F.first_pass(orc_en, olex, words, scr)
+    assert want is not None and len(want) > 8 * len(words) + 32
+    d = torch.from_numpy(scr).cuda()
+    off = np.array([0, len(scr)], np.int32)
+    # the plain C call with too little room says how much it needs
+    n_seg, _ = lex.first_pass_raw(d, off, [words], max_seg=40)
+    assert n_seg[0] == -(2 + len(want))
+    n_seg, seg = lex.first_pass_raw(d, off, [words], max_seg=len(want))
+    assert n_seg[0] == len(want)
+    # decoder_alignment for a batch: alone, and beside a 30-word text
+    alone = ssw.forced_alignment(gpu_en, lex, d, off, [words])[0]
+    assert alone is not None
+    assert [(w, int(a[0]), int(a[0] + a[1] - 1)) for w, a in zip(alone["words"], alone["word_al"])] \
+        == [(w, s, e) for (w, s, e, _) in want]
+    long_text = ["go", "forward", "ten", "meters"] * 8
+    d2 = torch.from_numpy(np.concatenate([scr, scr])).cuda()
+    both = ssw.forced_alignment(gpu_en, lex, d2, np.array([0, len(scr), 2 * len(scr)], np.int32),
+                                [words, long_text])
+    assert both[0] is not None
+    assert both[0]["words"] == alone["words"]
+    assert np.array_equal(both[0]["state_al"], alone["state_al"])
