@@ -77,11 +77,15 @@ int ssw_model_info(const ssw_model_t *m, ssw_model_info_t *out);
  * the CPU): REC float32 [cb*feat][density][32] = mean[0..15) | det[15] | scale[16..31);
  * SCAN_REC the same shape holding the quadratic form a[0..15) | c[15] | b[16..31);
  * SCAN_D0 float32 [cb*feat][32], element 0 = the codebook's reference det;
- * SCAN_EXACT uint32 [cb*feat][132] = count, then the densities scored in the exact form. */
+ * SCAN_EXACT uint32 [cb*feat][132] = count, then the densities scored in the exact form;
+ * SCAN_REC_MFMA / SCAN_EXACT_MFMA the same two for the matrix-core scan (its own error
+ * constant), SCAN_WFRAG uint16 (bf16) [cb*feat][4][2][3][64][8]: those records cut into three
+ * bf16 parts in MFMA A-fragment order. */
 enum ssw_table {
     SSW_TAB_MEAN = 0, SSW_TAB_VAR, SSW_TAB_DET, SSW_TAB_PTM_MIXW, SSW_TAB_MS_PDF, SSW_TAB_TP,
     SSW_TAB_SSEQ, SSW_TAB_SEN2CB, SSW_TAB_LOGADD8, SSW_TAB_PHONE_SSID, SSW_TAB_PHONE_TMAT,
-    SSW_TAB_REC, SSW_TAB_SCAN_REC, SSW_TAB_SCAN_D0, SSW_TAB_SCAN_EXACT
+    SSW_TAB_REC, SSW_TAB_SCAN_REC, SSW_TAB_SCAN_D0, SSW_TAB_SCAN_EXACT,
+    SSW_TAB_SCAN_REC_MFMA, SSW_TAB_SCAN_EXACT_MFMA, SSW_TAB_SCAN_WFRAG
 };
 const void *ssw_model_table(const ssw_model_t *m, int which, size_t *nbytes);
 

@@ -23,6 +23,8 @@ extern "C" {
 #define SSW_MAX_VECLEN 15
 /* per codebook-stream: [0] count, [1..] codewords the quadratic scan leaves to the exact form */
 #define SSW_EXLIST_STRIDE 132
+/* bf16 MFMA scan: bf16 values per (codebook, stream) in wfrag */
+#define SSW_WFRAG_PER_CBF (4 * 2 * 3 * 64 * 8)
 
 /* Host-side model: every table derived exactly as the reference derives it. */
 typedef struct ssw_host_model_s {
@@ -39,6 +41,15 @@ typedef struct ssw_host_model_s {
     float *rec, *recq, *recd0;
     uint32_t *exlist;
     int32_t n_exact_form;
+    /* the same scan for the matrix cores (ssw_k1a_mfma.inc): quadratic-form records whose
+     * constant carries the error bound of the split-bf16 MFMA evaluation (recqm, exlistm as
+     * recq / exlist), and the records cut into three bf16 parts in MFMA A-fragment order:
+     *   wfrag [cb*feat][4 row blocks][2 K blocks][3 parts][64 lanes][8] bf16
+     * (lane l of a fragment: density 32*rb + l%32, K = 16*kb + 8*(l/32) .. +7) */
+    float *recqm;
+    uint32_t *exlistm;
+    uint16_t *wfrag;
+    int32_t n_exact_form_m;
     /* mdef */
     int32_t n_ciphone, n_phone, n_emit_state, n_ci_sen, n_sen, n_tmat, n_sseq, sil;
     uint16_t *sseq;

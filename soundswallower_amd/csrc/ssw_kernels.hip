@@ -15,6 +15,8 @@
  *                        the speculative one)
  *   ssw_k1a_frames.inc   ptm_topn_frames_kernel (speculative history-free top-N with a proof
  *                        test per pair), ms_topn_fixup_kernel
+ *   ssw_k1a_mfma.inc     ptm_topn_mfma_kernel: the same scan with its multiply-adds on the matrix
+ *                        cores (split-bf16 MFMA keys, exact re-evaluation and in-wave pass as above)
  *   ssw_k1b_senone.inc   ptm_senone_kernel (codebook_norm + senone_eval, src/ptm_mgau.c:264-403),
  *                        ptm_senone_frame_kernel (one frame, active sets), ms_senone_kernel
  *   ssw_k4_feat.inc      feat_1s_c_d_dd_kernel (batch CMN + 1s_c_d_dd, src/feat.c:271-326)
@@ -59,6 +61,7 @@ namespace {
 #include "ssw_dev_common.inc"
 #include "ssw_k1a_chain.inc"
 #include "ssw_k1a_frames.inc"
+#include "ssw_k1a_mfma.inc"
 #include "ssw_k1b_senone.inc"
 #include "ssw_k4_feat.inc"
 #include "ssw_k2_align.inc"

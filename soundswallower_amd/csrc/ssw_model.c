@@ -728,6 +728,130 @@ cmp_float(const void *a, const void *b)
  * and go on the codebook's exact-form list: the kernel evaluates them the reference's
  * way after the scan.  tests/test_scan_bound.py replays the kernel's arithmetic on the
  * CPU against these tables. */
+/* round-to-nearest-even float -> bf16 (as v_cvt_pk_bf16_f32 does for finite values) */
+static uint16_t
+bf16_rne(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+static float
+bf16_to_float(uint16_t b)
+{
+    uint32_t u = (uint32_t)b << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+
+/* x = p[0] + p[1] + p[2] + r with |r| <= 2^-24 |x|: three bf16 parts of a float; the residuals
+ * x - p[0] and x - p[0] - p[1] are exact in float arithmetic */
+static void
+bf16_split3(float x, uint16_t p[3])
+{
+    float r = x;
+    int i;
+    for (i = 0; i < 3; ++i) {
+        p[i] = bf16_rne(r);
+        r = r - bf16_to_float(p[i]);
+    }
+}
+
+/* Scan records for the matrix-core scan (csrc/ssw_k1a_mfma.inc).  The key of density i for
+ * frame x is the same quadratic form c + sum_j (a_j x_j + b_j x_j^2) as in recq, but W = (a, c, b)
+ * and X = (x, 1, x^2) are cut into three bf16 parts each and the six largest part products
+ * (1,1) (1,2) (2,1) (2,2) (1,3) (3,1) are accumulated by v_mfma_f32_32x32x16_bf16 in fp32.
+ * With u = 2^-24 and M = sum_k |W_k X_k| the key differs from the real number by at most
+ *     u M (x^2 rounded) + 2 u M (residuals of the two splits) + 2 u M (the three part products
+ *     left out) + 13 eps M (twelve chained MFMAs, each within eps of the exact sum of its
+ *     products and its C input; eps <= 8 u: tools/microbench/mfma_bf16_scan.hip measures 4.3 u
+ *     at worst on cancelling data, and tests/test_gpu_mfma_bound.py checks the resulting bound
+ *     on the device) = 109 u M, taken as K u M with K = 119.
+ * The reference's own fp32 value is within 13 u |det| + 17 u S of the real number, and
+ * M <= |det - d0| + 6 R + 3 S, S <= |det - d0| + |value - d0| as for recq, which gives the
+ * per-density constant (4K + 17) |det - d0| + 6K R + 13 |det| folded into c below (with slack)
+ * and the term (3K + 17) u |value - d0| the kernel adds to the one key it uses as a bound.
+ * Densities whose constant exceeds SSW_MFMA_MAX_BIAS score units keep an inert record and are
+ * evaluated in the exact form (exlistm). */
+#define SSW_MFMA_K 119.0
+#define SSW_MFMA_MAX_BIAS 64.0
+static int
+ssw_host_build_mfma_records(ssw_host_model_t *h)
+{
+    const int ncbf = h->n_cb * h->n_feat;
+    const size_t nrec = (size_t)ncbf * h->n_density;
+    const double u24 = 1.0 / 16777216.0;
+    int cbf, d, j, rb, kb, p, l, e;
+
+    h->recqm = NULL;
+    h->exlistm = NULL;
+    h->wfrag = NULL;
+    h->n_exact_form_m = 0;
+    if (h->n_density != 128)
+        return 0; /* the MFMA scan is built for 128 densities; other shapes use the FMA scan */
+    h->recqm = (float *)calloc(nrec * SSW_REC_FLOATS, sizeof(float));
+    h->exlistm = (uint32_t *)calloc((size_t)ncbf * SSW_EXLIST_STRIDE, sizeof(uint32_t));
+    h->wfrag = (uint16_t *)calloc((size_t)ncbf * SSW_WFRAG_PER_CBF, sizeof(uint16_t));
+    if (!h->recqm || !h->exlistm || !h->wfrag) {
+        ssw_set_error("out of memory building the MFMA scan records");
+        return -1;
+    }
+    for (cbf = 0; cbf < ncbf; ++cbf) {
+        uint32_t *xl = h->exlistm + (size_t)cbf * SSW_EXLIST_STRIDE;
+        const float d0 = h->recd0[(size_t)cbf * SSW_REC_FLOATS];
+        for (d = 0; d < h->n_density; ++d) {
+            const float *r = h->rec + ((size_t)cbf * h->n_density + d) * SSW_REC_FLOATS;
+            float *q = h->recqm + ((size_t)cbf * h->n_density + d) * SSW_REC_FLOATS;
+            const double det = r[SSW_REC_DET], delta = det - (double)d0;
+            double R = 0.0, bias, cc;
+            int finite = isfinite(det);
+            float cf;
+            for (j = 0; j < SSW_MAX_VECLEN; ++j) {
+                double mean = r[j], var = r[SSW_REC_VAR + j];
+                R += fabs(var) * mean * mean;
+                finite = finite && isfinite(mean) && isfinite(var) && var >= 0.0;
+            }
+            bias = 1.05 * u24
+                * ((4.0 * SSW_MFMA_K + 18.0) * fabs(delta) + (6.0 * SSW_MFMA_K + 2.0) * R
+                   + 14.0 * fabs(det));
+            if (!finite || !(bias <= SSW_MFMA_MAX_BIAS)) {
+                xl[1 + xl[0]++] = (uint32_t)d;
+                q[SSW_REC_DET] = -3.0e38f; /* a = b = 0: the key stays out of the way */
+                ++h->n_exact_form_m;
+                continue;
+            }
+            for (j = 0; j < SSW_MAX_VECLEN; ++j) {
+                q[j] = (float)(2.0 * (double)r[SSW_REC_VAR + j] * (double)r[j]);
+                q[SSW_REC_VAR + j] = -r[SSW_REC_VAR + j];
+            }
+            cc = delta - R + bias;
+            cf = (float)cc;
+            if ((double)cf < cc)
+                cf = nextafterf(cf, INFINITY);
+            q[SSW_REC_DET] = cf;
+        }
+        /* A fragments: K index k of the MFMA = float slot k of the record (a at 0..12, c at 15
+         * against X = 1, b at 16..28 against x^2; the other slots are zero on both sides) */
+        for (rb = 0; rb < 4; ++rb)
+            for (kb = 0; kb < 2; ++kb)
+                for (l = 0; l < 64; ++l)
+                    for (e = 0; e < 8; ++e) {
+                        const int dens = 32 * rb + (l & 31), k = 16 * kb + 8 * (l >> 5) + e;
+                        uint16_t parts[3];
+                        bf16_split3(h->recqm[((size_t)cbf * h->n_density + dens) * SSW_REC_FLOATS + k],
+                                    parts);
+                        for (p = 0; p < 3; ++p)
+                            h->wfrag[(size_t)cbf * SSW_WFRAG_PER_CBF
+                                     + ((((size_t)rb * 2 + kb) * 3 + p) * 64 + l) * 8 + e]
+                                = parts[p];
+                    }
+    }
+    return 0;
+}
+
 int
 ssw_host_build_records(ssw_host_model_t *h)
 {
@@ -803,7 +927,7 @@ ssw_host_build_records(ssw_host_model_t *h)
         }
     }
     free(dets);
-    return 0;
+    return ssw_host_build_mfma_records(h);
 }
 
 
@@ -889,6 +1013,9 @@ ssw_host_model_free(ssw_host_model_t *h)
     free(h->recq);
     free(h->recd0);
     free(h->exlist);
+    free(h->recqm);
+    free(h->exlistm);
+    free(h->wfrag);
     free(h->sseq);
     free(h->sen2cb);
     free(h->phone_ssid);
