@@ -110,6 +110,12 @@ int ssw_score_batch_host(ssw_model_t *m, int scorer, const float *feats, int32_t
 /* Debug/parity view of the PTM top-N state after normalisation for every frame of the last
  * ssw_score_batch* call: cw uint8 / score int32 laid out [n_frames][n_cb][n_feat][topn]. */
 int ssw_score_batch_topn(ssw_model_t *m, int32_t n_frames, uint8_t *cw, int32_t *score);
+/* Debug/parity view of the matrix-core scan: the raw keys (upper bounds of the densities,
+ * relative to the codebook's reference level SCAN_D0, before their widening) of codebook x
+ * stream `cbf` for every frame of d_feats, computed exactly as the scan computes them.
+ * keys: host float [n_frames][128]; inert rows (SCAN_EXACT_MFMA densities) read about -3e38. */
+int ssw_debug_scan_keys(ssw_model_t *m, const float *d_feats, int32_t n_frames, int32_t cbf,
+                        float *keys);
 /* Counters of the last PTM batch: [0] = (chain,frame) pairs the history-free pass could not
  * prove order-independent and handed to the exact sequential pass, [1] = pairs total. */
 int ssw_score_batch_stats(ssw_model_t *m, int64_t stats[2]);

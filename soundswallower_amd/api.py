@@ -25,7 +25,8 @@ _TABLES = {
     "sseq": (6, np.uint16), "sen2cb": (7, np.int16), "logadd8": (8, np.uint8),
     "phone_ssid": (9, np.int32), "phone_tmat": (10, np.int32),
     "rec": (11, np.float32), "scan_rec": (12, np.float32), "scan_d0": (13, np.float32),
-    "scan_exact": (14, np.uint32),
+    "scan_exact": (14, np.uint32), "scan_rec_mfma": (15, np.float32),
+    "scan_exact_mfma": (16, np.uint32), "scan_wfrag": (17, np.uint16),
 }
 
 
@@ -151,6 +152,18 @@ class Model:
                "ssw_score_batch_topn")
         assert cw.size == n_frames * n_cbf * self.topn
         return cw, sc
+
+    def debug_scan_keys(self, feats, cbf):
+        """Raw keys of the matrix-core scan for one codebook x stream: float32 [n_frames][128]."""
+        feats = np.ascontiguousarray(feats, np.float32).reshape(-1, self.veclen_total)
+        d = self.to_device(feats)
+        out = np.zeros((len(feats), 128), np.float32)
+        try:
+            _check(self._L.ssw_debug_scan_keys(self._m, d, len(feats), int(cbf), _ptr(out)),
+                   "ssw_debug_scan_keys")
+        finally:
+            self.device_free(d)
+        return out
 
     def set_kernel_timing(self, enable=True):
         _check(self._L.ssw_set_kernel_timing(self._m, int(bool(enable))), "ssw_set_kernel_timing")

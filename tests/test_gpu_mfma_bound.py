@@ -1,0 +1,78 @@
+"""The one property the matrix-core scan's correctness rests on, checked on the device: every
+key, widened the way the kernel widens the key it uses as a bound, is >= the reference's fp32
+density value.  (The candidates themselves are re-evaluated exactly and a wrong guess only costs
+an exact pass; a key BELOW the true value could hide a density and change a result.)  The MFMA's
+internal accumulation order is not specified, so this cannot be replayed on the CPU the way
+tests/test_scan_bound.py replays the FMA scan: ssw_debug_scan_keys returns the keys the scan
+computes, and they are compared with the reference arithmetic in numpy float32."""
+import numpy as np
+import pytest
+
+from soundswallower_amd.synth import synth_features
+
+pytestmark = pytest.mark.gpu
+
+WIDEN = np.float32(2.2649765e-05)        # SSW_MFMA_WIDEN, csrc/ssw_k1a_mfma.inc
+
+
+def _reference_densities(rec, x):
+    """rec float32 [128][32] exact records of one codebook x stream, x float32 [n][13]:
+    d = det - sum_j (x_j - m_j)^2 v_j with one rounding per operation (src/ptm_mgau.c:63-68)."""
+    mean, var, det = rec[:, 0:13], rec[:, 16:29], rec[:, 15]
+    d = np.broadcast_to(det, (len(x), 128)).astype(np.float32).copy()
+    for j in range(13):
+        diff = x[:, None, j] - mean[None, :, j]
+        sq = diff * diff
+        d = d - sq * var[None, :, j]
+    return d
+
+
+def _inputs(means, seed):
+    base = synth_features(means, 96, seed)
+    rng = np.random.default_rng(seed)
+    parts = [base, base * 8.0, base * 40.0, base * 0.01, -base, np.zeros((4, 39), np.float32),
+             (np.round(base * 4) / 4).astype(np.float32),
+             rng.normal(0, 3, (64, 39)).astype(np.float32),
+             rng.normal(0, 30, (32, 39)).astype(np.float32)]
+    return np.ascontiguousarray(np.concatenate(parts), np.float32)
+
+
+@pytest.mark.parametrize("name", ["en-us", "fr-fr"])
+def test_mfma_keys_bound_the_reference_densities(gpu_en, gpu_fr, means_en, means_fr, name):
+    gpu, means = (gpu_en, means_en) if name == "en-us" else (gpu_fr, means_fr)
+    n_cbf = gpu.n_cb * gpu.n_feat
+    rec = gpu.table("rec").reshape(n_cbf, 128, 32)
+    d0 = gpu.table("scan_d0").reshape(n_cbf, 32)[:, 0]
+    ex = gpu.table("scan_exact_mfma").reshape(n_cbf, 132)
+    feats = _inputs(means, 2718)
+    # on the means of the worst-conditioned densities too (largest precision terms)
+    var = rec[:, :, 16:29]
+    flat = np.argsort(var.max(axis=2).reshape(-1))[-64:]
+    rows = feats[:64].copy()
+    for i, k in enumerate(flat):
+        cbf, d = divmod(int(k), 128)
+        f = cbf % gpu.n_feat
+        rows[i, f * 13:(f + 1) * 13] = rec[cbf, d, 0:13]
+    feats = np.concatenate([feats, rows, rows * np.float32(1.0001)])
+    worst = 0.0
+    slack = []
+    for cbf in range(n_cbf):
+        f = cbf % gpu.n_feat
+        keys = gpu.debug_scan_keys(feats, cbf)                       # relative to d0[cbf]
+        ref = _reference_densities(rec[cbf], feats[:, f * 13:(f + 1) * 13])
+        live = np.ones(128, bool)
+        live[ex[cbf, 1:1 + ex[cbf, 0]]] = False                      # exact-form densities: inert rows
+        assert (keys[:, ~live] < -1e37).all()
+        k = keys[:, live]
+        ub = k + np.abs(k) * WIDEN + np.float32(1.0e-3)              # as the kernel widens its bound
+        ub = ub + np.float32(d0[cbf])
+        ub = ub + np.abs(ub) * np.float32(2.384185791015625e-07)
+        r = ref[:, live]
+        ok = np.isfinite(r)
+        gap = (ub.astype(np.float64) - r.astype(np.float64))[ok]
+        assert (gap >= 0).all(), (cbf, float(gap.min()))
+        worst = max(worst, float(-(gap.min())))
+        # how loose: the part of the gap that is not the (deliberate) constant
+        slack.append(float(np.median(gap)))
+    assert worst <= 0.0
+    assert np.median(slack) < 64.0, "bounds this loose would flag a large share of the pairs"

@@ -163,3 +163,38 @@ def test_scan_bound_on_a_hostile_model(oracle_mod, tmp_path):
         on_list[exl[cbf, 1:1 + exl[cbf, 0]]] = True
         k, r = key[:, ~on_list], ref[:, ~on_list]
         assert np.all(widen(k, d0[cbf]) >= r)
+
+
+def test_mfma_scan_records_are_consistent_with_the_fma_ones():
+    """The matrix-core scan's tables (csrc/ssw_model.c, ssw_host_build_mfma_records): the same
+    quadratic form as SCAN_REC with a larger error constant; the three bf16 parts of every record
+    element add up to it exactly; exact-form densities have inert rows.  (That the resulting keys
+    bound the reference values is checked on the device: tests/test_gpu_mfma_bound.py.)"""
+    for name in ("en-us", "fr-fr"):
+        m = ssw.Model(os.path.join(MODEL_ROOT, name), config={"device": -2})
+        n_cbf = m.n_cb * m.n_feat
+        rq = m.table("scan_rec").reshape(n_cbf, 128, 32)
+        rm = m.table("scan_rec_mfma").reshape(n_cbf, 128, 32)
+        exq = m.table("scan_exact").reshape(n_cbf, 132)
+        exm = m.table("scan_exact_mfma").reshape(n_cbf, 132)
+        wf = m.table("scan_wfrag").reshape(n_cbf, 4, 2, 3, 64, 8)
+        for cbf in range(n_cbf):
+            live_q = np.ones(128, bool)
+            live_q[exq[cbf, 1:1 + exq[cbf, 0]]] = False
+            live_m = np.ones(128, bool)
+            live_m[exm[cbf, 1:1 + exm[cbf, 0]]] = False
+            both = live_q & live_m
+            # same a and b; a larger constant (more error to cover)
+            assert np.array_equal(rq[cbf, both][:, :13], rm[cbf, both][:, :13])
+            assert np.array_equal(rq[cbf, both][:, 16:29], rm[cbf, both][:, 16:29])
+            assert (rm[cbf, both, 15] >= rq[cbf, both, 15]).all()
+            assert (rm[cbf, ~live_m, 15] < -1e37).all()
+        parts = (wf.astype(np.uint32) << 16).view(np.float32)
+        total = parts[:, :, :, 0] + parts[:, :, :, 1] + parts[:, :, :, 2]      # [cbf][rb][kb][lane][8]
+        back = np.zeros_like(rm)
+        for rb in range(4):
+            for kb in range(2):
+                for lane in range(64):
+                    k0 = 16 * kb + 8 * (lane >> 5)
+                    back[:, 32 * rb + (lane & 31), k0:k0 + 8] = total[:, rb, kb, lane, :]
+        assert np.array_equal(back, rm), name
