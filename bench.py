@@ -309,7 +309,8 @@ def main():
     n_frames = feats.shape[0]
 
     step = ScoreStep(torch, model, feats, utt_off)
-    spin_up(torch, step)
+    if not os.environ.get("SSW_BENCH_NO_SPIN"):   # (tools/pmc_pass.py: keep the trace short)
+        spin_up(torch, step)
     elapsed = timed_steps(torch, dist, backend, step, args.warmup, args.steps)
     k_ms = step.kernel_ms(max(1, min(args.steps, 50)))
     flagged, pairs = model.last_stats()
@@ -400,7 +401,8 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_source,
-                     "kernel": "PTM path of one step: ptm_topn_frames + ptm_senone",
+                     "kernel": "PTM path of one step: ptm_topn_mfma (or ptm_topn_frames, SSW_SCAN=fma) "
+                               "+ ptm_senone",
                      "kernel_ms": path_ms, "algorithmic_bytes_per_frame": ab["path"],
                      "kernel_src_sha": sha,
                      "note": "achieved = ALGORITHMIC (touched-bytes, SURVEY 8(d)) GB/s, not HBM "

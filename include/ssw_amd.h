@@ -104,6 +104,21 @@ enum ssw_scorer { SSW_SCORER_PTM = 0, SSW_SCORER_MS = 1 };
 /* device pointers, asynchronous on `stream` (a hipStream_t, NULL = default stream) */
 int ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_frames,
                     const int32_t *utt_off, int32_t n_utts, int16_t *d_out, void *stream);
+/* The same with the reference's history semantics made available to batches.  The reference
+ * never resets the PTM top-N history after start-up: it carries from utterance to utterance
+ * (acmod_start_utt only resets frame_idx, src/acmod.c:367) and across acmod_rewind from the
+ * first pass of forced alignment into the second (src/decoder.c:786-793, src/ptm_mgau.c:425-448);
+ * only the codeword ORDER matters (tie-breaks among equal truncated scores).
+ *   flags      SSW_SCORE_CARRY_UTTS: no reset at the utterance boundaries of the batch
+ *   carry_in   optional uint32 [n_cb * n_feat], 4 codewords packed best first: the order the
+ *              batch's first frame starts from (NULL = the reset history)
+ *   carry_out  optional uint32 [n_cb * n_feat]: the order after the batch's last frame (makes the
+ *              call synchronous) -- pass it as carry_in of the next call / the second pass.
+ * The ms scorer keeps no history: the three are ignored for it. */
+#define SSW_SCORE_CARRY_UTTS 1u
+int ssw_score_batch_ex(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_frames,
+                       const int32_t *utt_off, int32_t n_utts, int16_t *d_out, void *stream,
+                       uint32_t flags, const uint32_t *carry_in, uint32_t *carry_out);
 /* host pointers, synchronous: copies in, scores, copies out */
 int ssw_score_batch_host(ssw_model_t *m, int scorer, const float *feats, int32_t n_frames,
                          const int32_t *utt_off, int32_t n_utts, int16_t *out);

@@ -144,6 +144,31 @@ class Model:
                                        C.c_void_p(int(stream)) if stream else None),
                "ssw_score_batch")
 
+    def score_batch_carry(self, feats, utt_off=None, carry_in=None, carry_utts=False,
+                          scorer=SCORER_PTM):
+        """ssw_score_batch_ex on host features: returns (scores int16 [n][n_sen], carry_out
+        uint32 [n_cb * n_feat]); carry_in = the carry_out of an earlier call (or None)."""
+        feats = np.ascontiguousarray(feats, dtype=np.float32).reshape(-1, self.veclen_total)
+        n = feats.shape[0]
+        off = (np.array([0, n], np.int32) if utt_off is None
+               else np.ascontiguousarray(utt_off, np.int32))
+        out = np.zeros((n, self.n_sen), np.int16)
+        cin = None if carry_in is None else np.ascontiguousarray(carry_in, np.uint32)
+        cout = np.zeros(self.n_cb * self.n_feat, np.uint32)
+        if n == 0:
+            return out, (cin.copy() if cin is not None else np.full_like(cout, 0x03020100))
+        d_in = self.to_device(feats)
+        d_out = self.device_malloc(out.nbytes)
+        try:
+            _check(self._L.ssw_score_batch_ex(self._m, scorer, d_in, n, _ptr(off), len(off) - 1,
+                                              d_out, None, 1 if carry_utts else 0, _ptr(cin),
+                                              _ptr(cout)), "ssw_score_batch_ex")
+            _check(self._L.ssw_memcpy_d2h(_ptr(out), d_out, out.nbytes), "ssw_memcpy_d2h")
+        finally:
+            self.device_free(d_in)
+            self.device_free(d_out)
+        return out, cout
+
     def last_topn(self, n_frames):
         n_cbf = self.n_cb * self.n_feat
         cw = np.zeros((n_frames, self.n_cb, self.n_feat, self.topn), np.uint8)

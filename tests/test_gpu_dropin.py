@@ -282,3 +282,19 @@ def test_default_configuration_scores_through_the_gpu_scorer(gpu_en, orc_en, ora
     assert [(int(a), int(b)) for a, b in zip(ph_start, ph_dur)] == [(r[1], r[2]) for r in ref]
     assert [int(x) for x in ph_score] == REF_SCORES_DEFAULT
     g.free()
+
+
+def test_second_pass_scores_from_the_batch_api(oracle_mod, orc_en, gpu_en):
+    """decoder_alignment rewinds and scores every frame again WITHOUT resetting the top-N history
+    (src/decoder.c:786-793): the batch API reproduces the second pass's scores on all 278 frames
+    of the reference's recording when the second call starts from the first call's carry_out
+    (history-dependent frames in quantity: tests/test_gpu_ptm.py,
+    test_history_carried_between_calls_and_utterances)."""
+    from tests.test_oracle_e2e_goforward import goforward_features, two_pass_scores
+    feats = goforward_features(oracle_mod)
+    first, carry = gpu_en.score_batch_carry(feats)
+    second, _ = gpu_en.score_batch_carry(feats, carry_in=carry)
+    ref_first = orc_en.ptm_score_utt(feats)
+    ref_second = two_pass_scores(orc_en, feats)
+    assert np.array_equal(first, ref_first)
+    assert np.array_equal(second, ref_second)

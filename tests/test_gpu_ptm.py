@@ -264,3 +264,49 @@ def test_ptm_runs_of_history_dependent_frames_across_tiles(gpu_en, orc_en, means
     assert flagged >= 300, "the runs should put many pairs through the exact pass"
     assert np.array_equal(gcw.astype(np.int32), rcw)
     assert np.array_equal(got, ref)
+
+
+def _tie_heavy_features(orc, means, total, seed):
+    """runs of identical frames whose top-N lists tie (see the test above), so that many frames
+    depend on the carried history"""
+    rng = np.random.default_rng(seed)
+    cand = synth_features(means, 600, 31337)
+    cand = (np.round(cand * 8.0) / 8.0).astype(np.float32)
+    bad = _unprovable_pairs(orc, means, cand)
+    ties = cand[np.argsort(-bad.reshape(len(cand), -1).sum(axis=1))[:6]]
+    filler = synth_features(means, 64, 999)
+    parts, pos, k = [], 0, 0
+    runs = [3, 331, 17, 140, 1, 129, 65, 64, 200]
+    while pos < total:
+        n = runs[k % len(runs)]
+        parts.append(filler[rng.integers(0, len(filler), n)] if k % 2 == 0
+                     else np.repeat(ties[(k // 2) % len(ties)][None], n, axis=0))
+        pos += n
+        k += 1
+    return np.ascontiguousarray(np.concatenate(parts)[:total], np.float32)
+
+
+def test_history_carried_between_calls_and_utterances(gpu_en, orc_en, means_en):
+    """ssw_score_batch_ex: the reference never resets its top-N history after start-up
+    (src/acmod.c:367, src/ptm_mgau.c:425-448).  (i) a chain scored in two calls, the second
+    starting from the first's carry_out, equals the chain scored in one piece, cut inside a run
+    of history-dependent frames; (ii) SSW_SCORE_CARRY_UTTS: utterance boundaries do not reset;
+    (iii) the plain call still resets.  Large calls (matrix-core scan) and small ones."""
+    feats = _tie_heavy_features(orc_en, means_en, 4700, 7)
+    ref_chain = orc_en.ptm_score_utt(feats)
+    for cut in (2400, 170):                 # the cut lies inside a run of identical frames
+        a, carry = gpu_en.score_batch_carry(feats[:cut])
+        b, carry2 = gpu_en.score_batch_carry(feats[cut:], carry_in=carry)
+        assert np.array_equal(np.concatenate([a, b]), ref_chain), cut
+        assert carry2.shape == (126,) and (carry2 != 0x03020100).any()
+    # without the carry the second piece starts from the reset history: the oracle's restart
+    b_reset, _ = gpu_en.score_batch_carry(feats[2400:])
+    assert np.array_equal(b_reset, orc_en.ptm_score_utt(feats[2400:]))
+    # utterance boundaries: reset by default, carried with the flag
+    off = np.array([0, 150, 2400, 2400, 4700], np.int32)
+    carried, _ = gpu_en.score_batch_carry(feats, off, carry_utts=True)
+    assert np.array_equal(carried, ref_chain)
+    plain = gpu_en.score_batch(feats, off)
+    ref_reset = np.concatenate([orc_en.ptm_score_utt(feats[off[u]:off[u + 1]])
+                                for u in range(len(off) - 1) if off[u + 1] > off[u]])
+    assert np.array_equal(plain, ref_reset)
