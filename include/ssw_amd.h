@@ -194,6 +194,25 @@ int ssw_align_batch(ssw_model_t *m, const int16_t *d_senscr, int32_t n_utts,
                     const int32_t *frame_off, const int32_t *phone_off, const uint16_t *senid,
                     const int16_t *tmatid, const int32_t *sf, const int32_t *ef,
                     ssw_align_entry_t *state_io, int32_t *status, void *stream);
+/* The same search in the reference's DEFAULT configuration (compallsen = no), scoring included:
+ * acmod scores only the senones of the HMMs the search has active (acmod_activate_hmm /
+ * acmod_flags2list, src/acmod.c:905-999 -- a uint8 delta list whose gaps above 255 list extra
+ * senones), the PTM scorer scans only the codebooks those senones belong to, normalises over
+ * them and subtracts the best LISTED score from every entry (src/ptm_mgau.c:264-403), and this
+ * search never clears acmod's set (src/state_align_search.c:186-189): frame t sees the seed --
+ * what the first pass left active, seed_active uint32 [n_utts][(n_sen + 31) / 32], bit b of
+ * word b / 32, or NULL -- plus the senones of every phone entered so far.  Which phones are
+ * entered when follows from sf / ef alone when those do not decrease along an utterance (the
+ * windows alignment_populate produces); otherwise the call is refused.  d_feats: feature rows
+ * [total_frames][veclen_total]; d_senscr: optional int16 [total_frames][n_sen] that receives
+ * the scores exactly as acmod->senone_scores would hold them frame by frame.  Other arguments
+ * and results as ssw_align_batch.  PTM scorer, history reset per utterance. */
+int ssw_align_batch_active(ssw_model_t *m, const float *d_feats, int32_t n_utts,
+                           const int32_t *frame_off, const int32_t *phone_off,
+                           const uint16_t *senid, const int16_t *tmatid, const int32_t *sf,
+                           const int32_t *ef, const uint32_t *seed_active,
+                           ssw_align_entry_t *state_io, int32_t *status, int16_t *d_senscr,
+                           void *stream);
 /* alignment_propagate (src/ps_alignment.c:316-352): sums children into parents.
  * parent[i] = index of child i's parent; parents must appear in non-decreasing order. */
 int ssw_alignment_propagate(const ssw_align_entry_t *child, const int32_t *parent,

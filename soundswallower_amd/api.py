@@ -227,6 +227,30 @@ class Model:
                "ssw_align_batch")
         return states, status
 
+    def align_batch_active(self, d_feats, frame_off, phone_off, senid, tmatid, sf=None, ef=None,
+                           seed_active=None, state_init=None, d_senscr=None, stream=None):
+        """ssw_align_batch_active: scoring over the search's active senones (compallsen = no) +
+        forced alignment; returns (states[n,3] int32, status[n_utts])."""
+        frame_off = np.ascontiguousarray(frame_off, np.int32)
+        phone_off = np.ascontiguousarray(phone_off, np.int32)
+        senid = np.ascontiguousarray(senid, np.uint16).reshape(-1, 3)
+        n_ph = senid.shape[0]
+        tmatid = np.ascontiguousarray(tmatid, np.int16)
+        sf = np.zeros(n_ph, np.int32) if sf is None else np.ascontiguousarray(sf, np.int32)
+        ef = (np.full(n_ph, INT_MAX, np.int32) if ef is None
+              else np.ascontiguousarray(ef, np.int32))
+        states = (np.zeros((n_ph * 3, 3), np.int32) if state_init is None
+                  else np.ascontiguousarray(state_init, np.int32).copy())
+        n_utts = len(frame_off) - 1
+        status = np.zeros(n_utts, np.int32)
+        seed = None if seed_active is None else np.ascontiguousarray(seed_active, np.uint32)
+        _check(self._L.ssw_align_batch_active(
+            self._m, _ptr(d_feats), n_utts, _ptr(frame_off), _ptr(phone_off), _ptr(senid),
+            _ptr(tmatid), _ptr(sf), _ptr(ef), _ptr(seed), _ptr(states), _ptr(status),
+            _ptr(d_senscr), C.c_void_p(int(stream)) if stream else None),
+            "ssw_align_batch_active")
+        return states, status
+
     def propagate(self, child, parent, n_parent):
         child = np.ascontiguousarray(child, np.int32)
         parent = np.ascontiguousarray(parent, np.int32)

@@ -72,6 +72,7 @@ namespace {
 #include "ssw_host_model.inc"
 #include "ssw_host_score.inc"
 #include "ssw_host_align.inc"
+#include "ssw_host_active.inc"
 #include "ssw_host_mgau.inc"
 #include "ssw_host_search.inc"
 #include "ssw_host_feat.inc"
