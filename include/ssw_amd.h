@@ -460,6 +460,11 @@ void ssw_device_free(void *d_ptr);
 int ssw_memcpy_h2d(void *d_dst, const void *src, size_t nbytes);
 int ssw_memcpy_d2h(void *dst, const void *d_src, size_t nbytes);
 int ssw_device_synchronize(void);
+/* independent (non-blocking) streams for the `stream` arguments above, e.g. to score the next
+ * chunk of a job while ssw_align_batch works through the previous one */
+void *ssw_stream_create(void);
+void ssw_stream_destroy(void *stream);
+int ssw_stream_synchronize(void *stream);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,14 @@ def lib() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with __graft_entry__.build() or "
             f"`make -C {CSRC}`; soundswallower_amd has no CPU fallback")
+    # A PyTorch-ROCm wheel bundles its own HIP / HSA / RCCL.  A process must not end up with two
+    # of them (the library's RCCL gather would talk to an HSA runtime nobody initialised:
+    # "no ROCm-capable device is detected"), so when torch is installed it goes first and the
+    # library binds to the copies torch has loaded.  A C host without torch uses /opt/rocm's.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
     L.ssw_config_defaults.argtypes = [C.POINTER(SswConfig)]
@@ -176,6 +184,10 @@ def lib() -> C.CDLL:
     L.ssw_comm_free.argtypes = [vp]
     L.ssw_comm_free.restype = None
     L.ssw_gather_alignments.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.ssw_stream_create.restype = vp
+    L.ssw_stream_destroy.argtypes = [vp]
+    L.ssw_stream_destroy.restype = None
+    L.ssw_stream_synchronize.argtypes = [vp]
     L.ssw_device_malloc.restype = vp
     L.ssw_device_malloc.argtypes = [sz]
     L.ssw_device_free.argtypes = [vp]

@@ -43,6 +43,7 @@ class Config5Shard:
                       else np.zeros((0, model.n_emit_state), np.uint16))
         self.tmat = np.concatenate(tmat) if tmat else np.zeros(0, np.int16)
         self.d_feats, self.d_scr = None, None
+        self.s_score = self.s_align = None
         if self.mine:
             # uploaded chunk by chunk: the host never holds more than one chunk of features
             row = model.veclen_total * 4
@@ -51,39 +52,66 @@ class Config5Shard:
                 f = synth_features(means, n_frames, 12345 + u)
                 model._L.ssw_memcpy_h2d(self.d_feats + k * n_frames * row,
                                         f.ctypes.data, f.nbytes)
-            self.d_scr = model.device_malloc(self.chunk_utts * n_frames * model.n_sen * 2)
+            nbytes = self.chunk_utts * n_frames * model.n_sen * 2
+            self.d_scr = model.device_malloc(2 * nbytes)      # two score buffers, ping-pong
+            self.d_scr2 = (self.d_scr, self.d_scr + nbytes)
+            self.s_score = model._L.ssw_stream_create()
+            self.s_align = model._L.ssw_stream_create()
 
     def close(self):
         for p in (self.d_feats, self.d_scr):
             if p:
                 self.model.device_free(p)
         self.d_feats = self.d_scr = None
+        for st in (self.s_score, self.s_align):
+            if st:
+                self.model._L.ssw_stream_destroy(st)
+        self.s_score = self.s_align = None
 
     def score_and_align(self):
-        """Scores and aligns the shard chunk by chunk.  Returns (states int32 [n_mine * 3P][3],
-        status int32 [n_mine], score_s, align_s)."""
-        m, F, P = self.model, self.n_frames, self.n_phones
+        """Scores and aligns the shard chunk by chunk.  Scoring is asynchronous on a stream of
+        its own and one chunk ahead of the (synchronous, latency-bound) alignment, which leaves
+        most of the chip to it: chunk k + 1 is scored while chunk k is aligned, into the other
+        of two score buffers.  Returns (states int32 [n_mine * 3P][3], status int32 [n_mine],
+        score_s, align_s) -- score_s is what the host still waits for scores, align_s the
+        alignment calls."""
+        m, F, P, L = self.model, self.n_frames, self.n_phones, self.model._L
         n_mine = len(self.mine)
         states = np.zeros((n_mine * P * 3, 3), np.int32)
         status = np.zeros(n_mine, np.int32)
         t_score = t_align = 0.0
         row = m.veclen_total * 4
-        for c0 in range(0, n_mine, self.chunk_utts):
-            c1 = min(n_mine, c0 + self.chunk_utts)
+        chunks = [(c0, min(n_mine, c0 + self.chunk_utts)) for c0 in range(0, n_mine, self.chunk_utts)]
+        if not chunks:
+            return states, status, 0.0, 0.0
+
+        def launch_score(k):
+            c0, c1 = chunks[k]
+            n = c1 - c0
+            frame_off = (np.arange(n + 1) * F).astype(np.int32)
+            m.score_batch_device(self.d_feats + c0 * F * row, n * F, frame_off, self.d_scr2[k & 1],
+                                 self.s_score)
+
+        t0 = time.perf_counter()
+        launch_score(0)
+        for k, (c0, c1) in enumerate(chunks):
             n = c1 - c0
             frame_off = (np.arange(n + 1) * F).astype(np.int32)
             phone_off = (np.arange(n + 1) * P).astype(np.int32)
-            t0 = time.perf_counter()
-            m.score_batch_device(self.d_feats + c0 * F * row, n * F, frame_off, self.d_scr)
-            m._L.ssw_device_synchronize()
-            t1 = time.perf_counter()
-            st, stat = m.align_batch(self.d_scr, frame_off, phone_off,
-                                     self.senid[c0 * P:c1 * P], self.tmat[c0 * P:c1 * P])
-            t2 = time.perf_counter()
+            ta = time.perf_counter()
+            L.ssw_stream_synchronize(self.s_score)          # chunk k's scores are complete
+            tb = time.perf_counter()
+            if k + 1 < len(chunks):
+                launch_score(k + 1)                           # runs beside the alignment below
+            st, stat = m.align_batch(self.d_scr2[k & 1], frame_off, phone_off,
+                                     self.senid[c0 * P:c1 * P], self.tmat[c0 * P:c1 * P],
+                                     stream=self.s_align)
+            tc = time.perf_counter()
             states[c0 * P * 3:c1 * P * 3] = st
             status[c0:c1] = stat
-            t_score += t1 - t0
-            t_align += t2 - t1
+            t_score += tb - ta
+            t_align += tc - tb
+        t_score += 0.0 * (time.perf_counter() - t0)
         return states, status, t_score, t_align
 
     def run(self, dist=None, device=None, comm=None):

@@ -223,6 +223,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--model", default="en-us")
     ap.add_argument("--mode", default="ptm", choices=["ptm", "ms", "align", "first_pass", "text"])
+    ap.add_argument("--max-len", type=int, default=400,
+                    help="ptm / ms: utterances of up to this many frames, 1-5 per batch (the "
+                         "matrix-core scan takes batches from ~2100 frames: use 1600)")
     a = ap.parse_args()
     if a.mode == "first_pass":
         return soak_first_pass(a)
@@ -258,7 +261,7 @@ def main():
     kinds = {}
     while time.time() - t0 < a.seconds:
         kind = ["synthetic", "scaled", "gauss", "interp", "quantised", "mixed"][n_batches % 6]
-        lens = rng.integers(1, 400, size=int(rng.integers(1, 6))).tolist()
+        lens = rng.integers(1, a.max_len, size=int(rng.integers(1, 6))).tolist()
         n = int(sum(lens))
         base = synth_features(means, n, int(rng.integers(1, 2**31)))
         if kind == "scaled":
@@ -297,7 +300,8 @@ def main():
         flagged += f
         pairs += p
         kinds[kind] = kinds.get(kind, 0) + n
-    print(json.dumps({"mode": a.mode, "model": a.model, "batches": n_batches, "frames": n_frames,
+    print(json.dumps({"mode": a.mode, "model": a.model, "max_len": a.max_len,
+                      "batches": n_batches, "frames": n_frames,
                       "frames_by_kind": kinds, "rows_differing": bad_rows,
                       "frames_with_topn_order_differing": bad_topn,
                       "exact_pass_share": flagged / max(pairs, 1),
