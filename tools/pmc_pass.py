@@ -35,7 +35,11 @@ def main():
     os.chdir(ROOT)
     env = dict(os.environ, TMPDIR="/tmp", SSW_BENCH_NO_SPIN="1")
     per = collections.defaultdict(dict)
-    for cs in SETS:
+    sets = list(SETS)
+    if os.environ.get("SSW_PMC_EXTRA"):     # "A,B;C,D": further counter sets, one pass each
+        only = os.environ.get("SSW_PMC_ONLY_EXTRA")
+        sets = ([] if only else sets) + [x.split(",") for x in os.environ["SSW_PMC_EXTRA"].split(";")]
+    for cs in sets:
         out = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}", "+".join(cs))
         os.makedirs(out, exist_ok=True)
         cmd = ["rocprofv3", "--pmc", *cs, "--kernel-trace", "--output-format", "csv", "-d", out,
