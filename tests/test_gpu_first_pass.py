@@ -245,9 +245,11 @@ def test_large_batch_equals_one_by_one(oracle_mod, gpu_en, orc_en):
     bad[50] = bad[50] + ["qqqqq"]
     with pytest.raises(ssw.SswError, match="Unknown word qqqqq"):
         _first_pass(gpu_en, lex, scores, bad)
-    # a text with more phone-tree HMMs than a workgroup can hold is refused, not truncated
-    with pytest.raises(ssw.SswError, match="phone-tree HMMs"):
-        _first_pass(gpu_en, lex, [scores[0]], [[vocab[int(x * len(vocab))] for x in lcg_uniform(5, 800)]])
+    # a text with more phone-tree HMMs than a workgroup can hold goes through the kernel that
+    # keeps them in HBM; a few frames of audio cannot reach the end of 800 words
+    long_text = [vocab[int(x * len(vocab))] for x in lcg_uniform(5, 800)]
+    assert len(lex.first_pass_graph(long_text)[0]) > 4096
+    assert _first_pass(gpu_en, lex, [scores[0]], [long_text]) == [None]
 
 
 def test_alternates_pronounced_alike(oracle_mod, gpu_fr, orc_fr):
@@ -450,3 +452,65 @@ def test_many_filler_segments_for_a_short_text(oracle_mod, gpu_en, orc_en):
     assert both[0] is not None
     assert both[0]["words"] == alone["words"]
     assert np.array_equal(both[0]["state_al"], alone["state_al"])
+
+
+def _forced_big(monkeypatch):
+    monkeypatch.setenv("SSW_FP_KERNEL", "big")
+
+
+def test_hbm_resident_kernel_equals_the_register_one(oracle_mod, gpu_en, gpu_fr, orc_en, orc_fr,
+                                                     monkeypatch):
+    """first_pass_big_kernel (node state in HBM, for texts beyond 4096 phone-tree HMMs) forced
+    on small problems (SSW_FP_KERNEL=big): noisy en-us paths with near-ties and failures, and the
+    fr-fr alternates that are pronounced alike (the twins' list-order bookkeeping); equal to the
+    register kernel and to the oracle."""
+    F, olex = _olex(oracle_mod, orc_en, "en-us")
+    lex = _lex(gpu_en, "en-us")
+    vocab = [w for w in olex.order[:olex.filler_start] if "(" not in w]
+    u = lcg_uniform(7, 24 * 10)
+    texts, scores = [], []
+    for t in range(24):
+        n = 1 + int(u[t * 10] * 8)
+        texts.append([vocab[int(x * len(vocab))] for x in u[t * 10 + 1:t * 10 + 1 + n]])
+        scores.append(synth_scores(F, orc_en, olex, texts[-1], 100 + t, orc_en.n_sen,
+                                   noise_lo=120 if t % 4 else 25))
+    small = _first_pass(gpu_en, lex, scores, texts)
+    Ff, olexf = _olex(oracle_mod, orc_fr, "fr-fr")
+    lexf = _lex(gpu_fr, "fr-fr")
+    textsf, scoresf = [], []
+    for t in range(24):
+        words = [["abus", "ait", "mauritaniens"], ["ait", "abus"], ["mauritaniens", "abus", "abus"],
+                 ["abus"]][t % 4]
+        textsf.append(words)
+        scoresf.append(synth_scores(Ff, orc_fr, olexf, words, 300 + t, orc_fr.n_sen, sil_p=0.5))
+    smallf = _first_pass(gpu_fr, lexf, scoresf, textsf)
+    _forced_big(monkeypatch)
+    big = _first_pass(gpu_en, lex, scores, texts)
+    bigf = _first_pass(gpu_fr, lexf, scoresf, textsf)
+    assert big == small and bigf == smallf
+    assert sum(g is not None for g in big) >= 12 and all(g is not None for g in bigf)
+    for t in range(0, 24, 5):
+        want = F.first_pass(orc_en, olex, texts[t], scores[t])
+        assert (want is None and big[t] is None) or \
+            [(w, s, s + d - 1, sc) for (w, s, d, sc) in big[t]] == want
+
+
+@pytest.mark.timeout(900)
+def test_a_page_of_2000_words(oracle_mod, gpu_en, orc_en):
+    """a 2,000-word text (about 19 K phone-tree HMMs, 8 K word-final ones,
+    ~90 K frames) through the HBM-resident first pass: the word segmentation of the oracle's
+    fsg_search, word for word and frame for frame."""
+    import time
+    F, olex = _olex(oracle_mod, orc_en, "en-us")
+    lex = _lex(gpu_en, "en-us")
+    vocab = [w for w in olex.order[:olex.filler_start] if "(" not in w]
+    words = [vocab[int(x * len(vocab))] for x in lcg_uniform(11, 2000)]
+    assert len(lex.first_pass_graph(words, max_nodes=1 << 17)[0]) > 4 * 4096
+    scr = synth_scores(F, orc_en, olex, words, 5, orc_en.n_sen, sil_p=0.1)
+    t0 = time.time()
+    got = _first_pass(gpu_en, lex, [scr], [words])[0]
+    t1 = time.time()
+    want = F.first_pass(orc_en, olex, words, scr)
+    print(f"2000 words, {len(scr)} frames: GPU first pass {t1 - t0:.2f} s, oracle {time.time() - t1:.2f} s")
+    assert want is not None and got is not None and len(got) >= 2000
+    assert [(w, s, s + d - 1, x) for (w, s, d, x) in got] == want
