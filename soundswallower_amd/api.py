@@ -655,20 +655,36 @@ def forced_align_planned(model: Model, lex: Lexicon, plan: FirstPassPlan, d_sens
     return AlignmentSet(L, h, lex)
 
 
+class Texts:
+    """The texts of a batch as the C calls take them (word_off + char **), marshalled once:
+    turning a few thousand Python strings into a ctypes array costs about a millisecond, which a
+    caller that aligns the same texts again (or a C host) does not pay."""
+
+    def __init__(self, texts):
+        self.n_utts = len(texts)
+        self.word_off = np.zeros(self.n_utts + 1, np.int32)
+        self.word_off[1:] = np.cumsum([len(t) for t in texts])
+        self._flat = [w.encode() for t in texts for w in t]
+        self.arr = (C.c_char_p * max(1, len(self._flat)))(*self._flat)
+        self.max_words = max((len(t) for t in texts), default=0)
+
+    def __len__(self):
+        return self.n_utts
+
+
 def align_text_batch(model: Model, lex: Lexicon, d_feats, utt_off, texts, cfg=None,
                      scorer=SCORER_PTM, stream=None) -> AlignmentSet:
-    """ssw_align_text_batch: feature rows in HBM + texts -> alignments (scoring, first pass,
-    populate, constrained state alignment, propagate) in one C call."""
+    """ssw_align_text_batch: feature rows in HBM + texts (list of word lists, or a Texts) ->
+    alignments (scoring, first pass, populate, constrained state alignment, propagate) in one C
+    call."""
     off = np.ascontiguousarray(utt_off, np.int32)
     n_utts = len(off) - 1
-    word_off = np.zeros(n_utts + 1, np.int32)
-    word_off[1:] = np.cumsum([len(t) for t in texts])
-    flat = [w.encode() for t in texts for w in t]
-    arr = (C.c_char_p * max(1, len(flat)))(*flat)
+    tx = texts if isinstance(texts, Texts) else Texts(texts)
+    assert tx.n_utts == n_utts
     L = _lib.lib()
     h = L.ssw_align_text_batch(model._m, lex._d, None if cfg is None else C.byref(cfg), scorer,
-                               _ptr(d_feats), int(off[-1]), _ptr(off), n_utts, _ptr(word_off), arr,
-                               _ptr(stream))
+                               _ptr(d_feats), int(off[-1]), _ptr(off), n_utts, _ptr(tx.word_off),
+                               tx.arr, _ptr(stream))
     if not h:
         raise SswError("ssw_align_text_batch: " + _lib.last_error())
     return AlignmentSet(L, h, lex)

@@ -592,6 +592,93 @@ ssw_host_threads(void)
     return n < 1 ? 1 : n;
 }
 
+/* A small persistent pool for the per-utterance host work of a batch (graph building here,
+ * alignment_populate in ssw_host_firstpass.inc): starting and joining a dozen threads costs
+ * more than the work they share at batch sizes of a few hundred utterances.  The workers are
+ * created on first use (SSW_HOST_THREADS - 1 of them; the caller takes chunks too) and sleep on
+ * a condition variable between calls.  One job at a time; fn must not call back into the pool. */
+static struct {
+    pthread_mutex_t job_mu, mu;
+    pthread_cond_t cv_work, cv_done;
+    int n_workers, started;
+    void (*fn)(void *, int);
+    void *arg;
+    int n_chunks, next, done;
+    unsigned gen;
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER,
+             PTHREAD_COND_INITIALIZER, 0, 0, NULL, NULL, 0, 0, 0, 0u };
+
+static void
+pool_take_chunks(void)
+{
+    for (;;) {
+        int k;
+        pthread_mutex_lock(&g_pool.mu);
+        k = g_pool.next < g_pool.n_chunks ? g_pool.next++ : -1;
+        pthread_mutex_unlock(&g_pool.mu);
+        if (k < 0)
+            return;
+        g_pool.fn(g_pool.arg, k);
+        pthread_mutex_lock(&g_pool.mu);
+        if (++g_pool.done == g_pool.n_chunks)
+            pthread_cond_broadcast(&g_pool.cv_done);
+        pthread_mutex_unlock(&g_pool.mu);
+    }
+}
+
+static void *
+pool_worker(void *unused)
+{
+    unsigned seen = 0;
+    (void)unused;
+    for (;;) {
+        pthread_mutex_lock(&g_pool.mu);
+        while (g_pool.gen == seen)
+            pthread_cond_wait(&g_pool.cv_work, &g_pool.mu);
+        seen = g_pool.gen;
+        pthread_mutex_unlock(&g_pool.mu);
+        pool_take_chunks();
+    }
+    return NULL;
+}
+
+void
+ssw_parallel_for(int n_chunks, void (*fn)(void *, int), void *arg)
+{
+    int k;
+    if (n_chunks <= 1 || ssw_host_threads() < 2) {
+        for (k = 0; k < n_chunks; ++k)
+            fn(arg, k);
+        return;
+    }
+    pthread_mutex_lock(&g_pool.job_mu);
+    if (!g_pool.started) {
+        const int want = ssw_host_threads() - 1 > 31 ? 31 : ssw_host_threads() - 1;
+        g_pool.started = 1;
+        for (k = 0; k < want; ++k) {
+            pthread_t t;
+            if (pthread_create(&t, NULL, pool_worker, NULL) != 0)
+                break;
+            pthread_detach(t);
+            ++g_pool.n_workers;
+        }
+    }
+    pthread_mutex_lock(&g_pool.mu);
+    g_pool.fn = fn;
+    g_pool.arg = arg;
+    g_pool.n_chunks = n_chunks;
+    g_pool.next = g_pool.done = 0;
+    ++g_pool.gen;
+    pthread_cond_broadcast(&g_pool.cv_work);
+    pthread_mutex_unlock(&g_pool.mu);
+    pool_take_chunks();
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.done < g_pool.n_chunks)
+        pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
+    pthread_mutex_unlock(&g_pool.mu);
+    pthread_mutex_unlock(&g_pool.job_mu);
+}
+
 /* Texts are independent: large batches are built by a few threads, each over a contiguous
  * range of utterances, and the pieces are concatenated (indices are local to an utterance;
  * only the offsets tables need rebasing). */
@@ -606,17 +693,16 @@ typedef struct {
     char err[512]; /* the error text is thread-local: carried back by hand */
 } build_job_t;
 
-static void *
-build_thread(void *arg)
+static void
+build_chunk(void *arg, int k)
 {
-    build_job_t *j = (build_job_t *)arg;
+    build_job_t *j = (build_job_t *)arg + k;
     j->out = graphs_build_serial(j->m, j->d, j->cfg, j->n_utts, j->word_off, j->words);
     j->err[0] = '\0';
     if (j->out == NULL) {
         strncpy(j->err, ssw_last_error(), sizeof(j->err) - 1);
         j->err[sizeof(j->err) - 1] = '\0';
     }
-    return NULL;
 }
 
 #define CAT(field, count_field, type)                                                        \
@@ -641,8 +727,6 @@ ssw_fp_graphs_build(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_p
 {
     enum { MAX_THR = 32, MIN_PER_THR = 16 };
     build_job_t job[MAX_THR];
-    pthread_t thr[MAX_THR];
-    int started[MAX_THR];
     ssw_fp_graphs_t *g, total;
     int n_thr = n_utts / MIN_PER_THR, t, ok = 1, u;
     const int cap = ssw_host_threads();
@@ -661,14 +745,10 @@ ssw_fp_graphs_build(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_p
         job[t].word_off = word_off + u0;
         job[t].words = words + word_off[u0];
         job[t].out = NULL;
-        started[t] = pthread_create(&thr[t], NULL, build_thread, &job[t]) == 0;
-        if (!started[t])
-            build_thread(&job[t]);
     }
+    ssw_parallel_for(n_thr, build_chunk, job);
     memset(&total, 0, sizeof(total));
     for (t = 0; t < n_thr; ++t) {
-        if (started[t])
-            pthread_join(thr[t], NULL);
         if (job[t].out == NULL) {
             if (ok)
                 ssw_set_error("%s", job[t].err);

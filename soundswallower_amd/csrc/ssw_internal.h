@@ -129,6 +129,8 @@ ssw_fp_graphs_t *ssw_fp_graphs_build(const ssw_model_t *m, const struct ssw_dict
                                      const int32_t *word_off, const char *const *words);
 void ssw_fp_graphs_free(ssw_fp_graphs_t *g);
 int ssw_host_threads(void);
+/* fn(arg, k) for k in [0, n_chunks) on a persistent pool of host threads + the caller */
+void ssw_parallel_for(int n_chunks, void (*fn)(void *arg, int chunk), void *arg);
 
 #ifdef __cplusplus
 }
