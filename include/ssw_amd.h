@@ -339,7 +339,9 @@ int ssw_first_pass_run(ssw_model_t *m, const ssw_first_pass_plan_t *plan, const 
  * (start, duration, score) -- read with the accessors below.  Arguments as
  * ssw_first_pass_batch.  Returns NULL on a call-level error; per-utterance outcomes are in
  * ssw_alignment_set_status: 0 aligned, 1 the first pass did not reach the end of the text,
- * 2 the second pass failed ("Failed to reach final state" / "Alignment failed in frame"). */
+ * 2 the second pass failed ("Failed to reach final state" / "Alignment failed in frame"),
+ * 3 the utterance's text was rejected (decoder_set_align_text's "Unknown word ..."; the message
+ * is in ssw_alignment_set_message) -- the other utterances of the batch are aligned all the same. */
 typedef struct ssw_alignment_set_s ssw_alignment_set_t;
 ssw_alignment_set_t *ssw_forced_align_batch(ssw_model_t *m, const ssw_dict_t *d,
                                             const ssw_first_pass_config_t *cfg,
@@ -363,6 +365,7 @@ ssw_alignment_set_t *ssw_align_text_batch(ssw_model_t *m, const ssw_dict_t *d,
                                           const int32_t *word_off, const char *const *words,
                                           void *stream);
 int32_t ssw_alignment_set_status(const ssw_alignment_set_t *a, int32_t utt);
+const char *ssw_alignment_set_message(const ssw_alignment_set_t *a, int32_t utt);
 /* each returns the number of entries and points the outputs (any may be NULL) at arrays owned
  * by the set: words -> dictionary ids; phones -> CI phone id and parent word index;
  * states -> senone id and parent phone = index / 3 */

@@ -153,6 +153,8 @@ def lib() -> C.CDLL:
     L.ssw_align_text_batch.argtypes = [vp, vp, vp, C.c_int, vp, i32, vp, i32, vp, vp, vp]
     L.ssw_alignment_set_status.restype = i32
     L.ssw_alignment_set_status.argtypes = [vp, i32]
+    L.ssw_alignment_set_message.restype = C.c_char_p
+    L.ssw_alignment_set_message.argtypes = [vp, i32]
     for fn in (L.ssw_alignment_set_words, L.ssw_alignment_set_states):
         fn.restype = i32
         fn.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]

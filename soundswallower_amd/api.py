@@ -560,6 +560,10 @@ class AlignmentSet:
     def status(self, u):
         return int(self._L.ssw_alignment_set_status(self._a, u))
 
+    def message(self, u):
+        """Why utterance u's text was rejected (status 3), else ''."""
+        return self._L.ssw_alignment_set_message(self._a, u).decode()
+
     def utterance(self, u):
         """None unless status 0; else dict(words, word_al, cipid, parent, phone_al, senid,
         state_al) with *_al int32 [n][3] = (start, duration, score)."""

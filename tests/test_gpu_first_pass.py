@@ -245,6 +245,22 @@ def test_large_batch_equals_one_by_one(oracle_mod, gpu_en, orc_en):
     bad[50] = bad[50] + ["qqqqq"]
     with pytest.raises(ssw.SswError, match="Unknown word qqqqq"):
         _first_pass(gpu_en, lex, scores, bad)
+    # ... of the low-level call; decoder_set_align_text rejects that ONE utterance
+    # (src/decoder.c:699-703) and so do the alignment calls: status 3 with the reference's
+    # message, every other utterance as before
+    d_feats_like = ssw.forced_align_batch(gpu_en, lex, d, off, bad)
+    assert d_feats_like.status(50) == 3 and d_feats_like.message(50) == "Unknown word qqqqq"
+    assert d_feats_like.utterance(50) is None and d_feats_like.message(49) == ""
+    a2 = ssw.forced_align_batch(gpu_en, lex, d, off, texts)
+    for i in range(64):
+        if i == 50:
+            continue
+        u1, u2 = d_feats_like.utterance(i), a2.utterance(i)
+        assert (u1 is None) == (u2 is None)
+        if u1 is not None:
+            assert u1["words"] == u2["words"] and np.array_equal(u1["state_al"], u2["state_al"])
+    d_feats_like.free()
+    a2.free()
     # a text with more phone-tree HMMs than a workgroup can hold goes through the kernel that
     # keeps them in HBM; a few frames of audio cannot reach the end of 800 words
     long_text = [vocab[int(x * len(vocab))] for x in lcg_uniform(5, 800)]
