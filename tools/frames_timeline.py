@@ -25,10 +25,12 @@ T = tl[:, :4].astype(np.int64)
 for x in np.unique(grp):
     T[grp == x] -= T[grp == x, 0].min()
 print("waves", len(tl), "clock units (s_memtime)")
-for k, nm in enumerate(("start", "loop begin", "loop end", "end")):
+# stamps of ptm_topn_mfma_kernel: 0 = LDS filled, 1 = first 64-frame step done, 2 = scan done
+# (= stamp 1 with one step per wave), 3 = exact in-wave pass done
+for k, nm in enumerate(("LDS filled", "1st step done", "scan done", "end")):
     print(f"{nm:11s} min {T[:,k].min():8d} p50 {int(np.median(T[:,k])):8d} p90 {int(np.percentile(T[:,k],90)):8d} max {T[:,k].max():8d}")
-print("loop duration p10/p50/p90/max", np.percentile(T[:,2]-T[:,1],[10,50,90,100]).astype(int))
-print("prologue p50/max", np.percentile(T[:,1]-T[:,0],[50,100]).astype(int), "epilogue p50/max", np.percentile(T[:,3]-T[:,2],[50,100]).astype(int))
+print("later steps p10/p50/p90/max", np.percentile(T[:,2]-T[:,1],[10,50,90,100]).astype(int))
+print("first step p50/max", np.percentile(T[:,1]-T[:,0],[50,100]).astype(int), "exact pass p50/max", np.percentile(T[:,3]-T[:,2],[50,100]).astype(int))
 hw = tl[:, 4].astype(np.int64); xcc = tl[:, 5].astype(np.int64) & 0xf
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; se = (hw >> 13) & 7
 key = xcc * 100000 + se * 1000 + cu * 10 + simd
