@@ -34,8 +34,8 @@ def test_align_matches_oracle(gpu_en, orc_en, n_phones, n_frames):
 def test_all_alignment_kernels_agree_on_a_ragged_windowed_batch(gpu_en, orc_en, monkeypatch):
     """Utterances of 1..200 phones in one call, with phone windows (sf/ef) on some of them and
     one window that cannot be met: the wave-per-word kernel (the default here), the
-    wave-per-utterance register kernel and the LDS kernel (SSW_ALIGN_KERNEL=mw/reg/lds) must all
-    equal the oracle, failures included."""
+    wave-per-utterance register kernel, the LDS kernel and the HBM-resident one
+    (SSW_ALIGN_KERNEL=mw/reg/lds/hbm) must all equal the oracle, failures included."""
     rng = np.random.default_rng(5)
     n_ph = [1, 3, 64, 65, 127, 128, 200, 17]
     n_fr = [int(p * rng.integers(3, 6) + 4) for p in n_ph]
@@ -68,7 +68,7 @@ def test_all_alignment_kernels_agree_on_a_ragged_windowed_batch(gpu_en, orc_en, 
     d = gpu_en.to_device(scr)
     try:
         results = []
-        for mode in ("mw", "reg", "lds"):
+        for mode in ("mw", "reg", "lds", "hbm"):
             monkeypatch.setenv("SSW_ALIGN_KERNEL", mode)
             results.append(gpu_en.align_batch(d, frame_off, phone_off, senid, tmat, sf=sf, ef=ef))
     finally:
@@ -81,9 +81,10 @@ def test_all_alignment_kernels_agree_on_a_ragged_windowed_batch(gpu_en, orc_en, 
                 assert np.array_equal(st[phone_off[u] * 3:phone_off[u + 1] * 3], rst), u
     assert np.array_equal(results[0][1], results[1][1])
     assert np.array_equal(results[0][1], results[2][1])
+    assert np.array_equal(results[0][1], results[3][1])
 
 
-@pytest.mark.parametrize("mode", ["reg", "lds"])
+@pytest.mark.parametrize("mode", ["reg", "lds", "hbm"])
 def test_other_alignment_kernels_match_oracle(gpu_en, orc_en, monkeypatch, mode):
     monkeypatch.setenv("SSW_ALIGN_KERNEL", mode)
     for n_phones, n_frames in ((64, 300), (65, 300), (150, 700), (256, 900)):
@@ -123,7 +124,7 @@ def test_skip_arc_topologies_match_oracle(orc_en, oracle_mod, monkeypatch, tmp_p
     assert np.array_equal(g.table("tp"), o.tp.reshape(-1))
     tp = o.tp
     assert (tp[:, 0, 2] < 255).any() and (tp[:, 0, 2] == 255).any() and (tp[:, 1, 3] < 255).any()
-    for mode in ("mw", "reg", "lds"):
+    for mode in ("mw", "reg", "lds", "hbm"):
         monkeypatch.setenv("SSW_ALIGN_KERNEL", mode)
         for n_phones, n_frames in ((6, 30), (70, 260), (150, 500)):
             senid, tmat, _ = synth_alignment_task(o.sseq, o.phone_ssid, o.phone_tmat, o.n_ciphone,
@@ -138,3 +139,29 @@ def test_skip_arc_topologies_match_oracle(orc_en, oracle_mod, monkeypatch, tmp_p
             assert (status[0] == 0) == (rv == 0), (mode, n_phones)
             assert rv == 0
             assert np.array_equal(st, rst), (mode, n_phones)
+
+
+@pytest.mark.timeout(600)
+def test_utterance_beyond_the_lds_limit(gpu_en, orc_en):
+    """3,000 phones (the LDS kernel holds 2,560): the HBM-resident kernel by itself, with windows
+    that keep the walked range short, equal to the oracle."""
+    n_phones, n_frames = 3000, 9500
+    senid, tmat, _ = synth_alignment_task(orc_en.sseq, orc_en.phone_ssid, orc_en.phone_tmat,
+                                          orc_en.n_ciphone, n_phones, 4242)
+    scr = _random_senscr(n_frames, orc_en.n_sen, 99)
+    mid = (np.arange(n_phones) * n_frames) // n_phones
+    sf = np.maximum(mid - 40, 0).astype(np.int32)
+    ef = np.minimum(mid + 60, n_frames).astype(np.int32)
+    rv, rst, _ = orc_en.state_align(scr, senid, tmat, sf=sf, ef=ef)
+    d = gpu_en.to_device(scr)
+    try:
+        st, status = gpu_en.align_batch(d, [0, n_frames], [0, n_phones], senid, tmat, sf=sf, ef=ef)
+        # ... and without windows: every phone from 0 to the frontier stays in the walked range
+        rv2, rst2, _ = orc_en.state_align(scr[:7000], senid[:2600], tmat[:2600])
+        st2, status2 = gpu_en.align_batch(d, [0, 7000], [0, 2600], senid[:2600], tmat[:2600])
+    finally:
+        gpu_en.device_free(d)
+    assert rv == 0 and status[0] == 0 and np.array_equal(st, rst)
+    assert (status2[0] == 0) == (rv2 == 0)
+    if rv2 == 0:
+        assert np.array_equal(st2, rst2)

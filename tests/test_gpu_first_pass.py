@@ -530,3 +530,29 @@ def test_a_page_of_2000_words(oracle_mod, gpu_en, orc_en):
     print(f"2000 words, {len(scr)} frames: GPU first pass {t1 - t0:.2f} s, oracle {time.time() - t1:.2f} s")
     assert want is not None and got is not None and len(got) >= 2000
     assert [(w, s, s + d - 1, x) for (w, s, d, x) in got] == want
+    # ... and the whole decoder_alignment: populate with those windows, the second pass over
+    # ~9,000 phones (HBM-resident state, a 20 GB token table), propagate; against the oracle's
+    # state_align_search on the same phones and windows
+    off = np.array([0, len(scr)], np.int32)
+    d = torch.from_numpy(np.ascontiguousarray(scr, np.int16)).cuda()
+    t2 = time.time()
+    aset = ssw.forced_align_batch(gpu_en, lex, d, off, [words])
+    t3 = time.time()
+    assert aset.status(0) == 0
+    a = aset.utterance(0)
+    aset.free()
+    assert a["words"] == [w for (w, _, _, _) in got] and len(a["cipid"]) > 2560
+    assert [tuple(int(x) for x in r[:2]) for r in a["word_al"]] == [(s, dd) for (_, s, dd, _) in got]
+    pop = lex.populate([w for (w, _, _, _) in got], [s for (_, s, _, _) in got],
+                       [dd for (_, _, dd, _) in got])
+    st, du = pop["start"], pop["duration"]
+    sf = np.maximum(st, 0).astype(np.int32)
+    ef = np.where(du > 0, st + du, 2**31 - 1).astype(np.int32)
+    senid = orc_en.sseq[pop["ssid"]].astype(np.uint16)
+    init = np.zeros((len(st) * 3, 3), np.int32)      # what alignment_populate leaves in the states
+    init[:, 0] = np.repeat(st, 3)
+    init[:, 1] = np.repeat(du, 3)
+    rv, rst, _ = orc_en.state_align(scr, senid, pop["tmatid"].astype(np.int16), sf=sf, ef=ef,
+                                    state_init=init)
+    print(f"decoder_alignment of the page: {t3 - t2:.2f} s, {len(a['cipid'])} phones; oracle second pass {time.time() - t3:.2f} s")
+    assert rv == 0 and np.array_equal(a["state_al"], rst)
