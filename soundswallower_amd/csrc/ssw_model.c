@@ -468,10 +468,22 @@ load_mdef(ssw_host_model_t *h, const char *path)
         ssw_set_error("%s: mixed-topology mdef not supported", path);
         goto bad;
     }
+    /* the counts size every table below: a damaged header must not become an allocation of
+     * -1 elements or an index past a row */
+    if (h->n_ciphone < 1 || h->n_ciphone > 255 || h->n_phone < h->n_ciphone || h->n_sen < 1
+        || h->n_sen > 0xffff || h->n_ci_sen < 0 || h->n_ci_sen > h->n_sen || h->n_tmat < 1
+        || h->n_sseq < 1 || n_tree < 0 || h->n_emit_state > 16) {
+        ssw_set_error("%s: implausible header (%d CI phones, %d phones, %d states, %d senones, "
+                      "%d tmats, %d senone sequences, %d tree nodes)", path, h->n_ciphone,
+                      h->n_phone, h->n_emit_state, h->n_sen, h->n_tmat, h->n_sseq, n_tree);
+        goto bad;
+    }
     /* CI names: n_ciphone NUL-terminated strings, block padded to 4 bytes */
     names = at = r.at;
     h->sil = -1;
     h->ciname = (char **)calloc((size_t)h->n_ciphone, sizeof(char *));
+    if (h->ciname == NULL)
+        goto oom;
     for (i = 0; i < h->n_ciphone; ++i) {
         const char *nm = (const char *)r.base + at;
         size_t l = strnlen(nm, r.size - at);
@@ -480,6 +492,8 @@ load_mdef(ssw_host_model_t *h, const char *path)
         if (l == 3 && memcmp(nm, "SIL", 3) == 0)
             h->sil = i;
         h->ciname[i] = (char *)malloc(l + 1);
+        if (h->ciname[i] == NULL)
+            goto oom;
         memcpy(h->ciname[i], nm, l + 1);
         at += l + 1;
     }
@@ -488,6 +502,8 @@ load_mdef(ssw_host_model_t *h, const char *path)
         goto trunc;
     h->n_cd_tree = n_tree;
     h->cd_tree = (struct ssw_cd_node_s *)malloc(sizeof(*h->cd_tree) * (size_t)(n_tree ? n_tree : 1));
+    if (h->cd_tree == NULL)
+        goto oom;
     for (i = 0; i < n_tree; ++i) {
         h->cd_tree[i].ctx = (int16_t)peek16(&r, at + 8 * (size_t)i);
         h->cd_tree[i].n_down = (int16_t)peek16(&r, at + 8 * (size_t)i + 2);
@@ -502,15 +518,25 @@ load_mdef(ssw_host_model_t *h, const char *path)
     if (at + 2 * n_sseq_words > r.size || n_sseq_words < (size_t)h->n_sseq * h->n_emit_state)
         goto trunc;
     h->sseq = (uint16_t *)malloc(2 * n_sseq_words);
+    if (h->sseq == NULL)
+        goto oom;
     for (i = 0; (size_t)i < n_sseq_words; ++i)
         h->sseq[i] = peek16(&r, at + 2 * (size_t)i);
+    for (i = 0; i < h->n_sseq * h->n_emit_state; ++i)
+        if (h->sseq[i] >= h->n_sen) { /* would index past a score row on the device */
+            ssw_set_error("%s: senone sequence %d names senone %d of %d", path,
+                          i / h->n_emit_state, h->sseq[i], h->n_sen);
+            goto bad;
+        }
 
     h->phone_ssid = (int32_t *)malloc(sizeof(int32_t) * (size_t)h->n_phone);
     h->phone_tmat = (int32_t *)malloc(sizeof(int32_t) * (size_t)h->n_phone);
     h->sen2cb = (int16_t *)malloc(sizeof(int16_t) * (size_t)h->n_sen);
+    h->ci_filler = (uint8_t *)calloc((size_t)h->n_ciphone, 1);
+    if (!h->phone_ssid || !h->phone_tmat || !h->sen2cb || !h->ci_filler)
+        goto oom;
     for (i = 0; i < h->n_sen; ++i)
         h->sen2cb[i] = -1;
-    h->ci_filler = (uint8_t *)calloc((size_t)h->n_ciphone, 1);
     for (i = 0; i < h->n_ciphone && i < h->n_phone; ++i)
         h->ci_filler[i] = r.base[phones + (size_t)i * 12 + 8]; /* info.ci.filler */
     for (i = 0; i < h->n_phone; ++i) {
@@ -528,6 +554,9 @@ load_mdef(ssw_host_model_t *h, const char *path)
     }
     rd_close(&r);
     return 0;
+oom:
+    ssw_set_error("%s: out of memory", path);
+    goto bad;
 trunc:
     ssw_set_error("%s: truncated", path);
 bad:

@@ -116,6 +116,24 @@ def test_corrupt_model_is_refused(lib, tmp_path):
     with pytest.raises(ssw.SswError):
         ssw.Model(mdef=os.path.join(src, "nope"), means=os.path.join(src, "means"),
                   variances=os.path.join(src, "variances"), config={"device": -2})
+    # a model definition whose header counts do not fit its tables: fewer senones than its
+    # senone sequences name (they would index past a score row), a negative count
+    import struct
+    raw = bytearray(open(os.path.join(src, "mdef"), "rb").read())
+    assert raw[:4] in (b"BMDF", b"FDMB")
+    fmt = "<" if raw[:4] == b"BMDF" else ">"
+    hd = 12 + struct.unpack(fmt + "i", raw[8:12])[0]          # magic, version, descriptor
+    n_sen = struct.unpack(fmt + "i", raw[hd + 16:hd + 20])[0]
+    for field, value, msg in ((4, n_sen - 100, "names senone"), (6, -5, "implausible header"),
+                              (1, 3, "implausible header")):
+        dmg = bytearray(raw)
+        dmg[hd + 4 * field:hd + 4 * field + 4] = struct.pack(fmt + "i", value)
+        path = tmp_path / f"mdef_{field}"
+        path.write_bytes(bytes(dmg))
+        with pytest.raises(ssw.SswError, match=msg):
+            ssw.Model(mdef=str(path), means=os.path.join(src, "means"),
+                      variances=os.path.join(src, "variances"), sendump=os.path.join(src, "sendump"),
+                      tmat=os.path.join(src, "transition_matrices"), config={"device": -2})
 
 
 def test_compute_fails_loudly_without_gpu(lib):
