@@ -9,6 +9,13 @@
  * kept per thread and returned by ssw_last_error()); constructors return NULL on error;
  * objects are freed by their *_free function.  Calls are synchronous unless a stream is passed.
  * Pointers named d_* are device (HIP) pointers, everything else is host memory.
+ *
+ * Threading: as the reference's decoder, a model is NOT re-entrant.  An ssw_model_t owns the
+ * workspaces its calls use (top-N block, alignment and first-pass arenas, cached utterance
+ * offsets, the score rows of ssw_align_text_batch): one call at a time per model, from any
+ * thread; calls on different models -- one per host thread or per stream of work -- run side by
+ * side.  Host-only calls (ssw_first_pass_prepare, ssw_alignment_populate, the dictionary and JSON
+ * functions) only read the model and may run beside a device call on it.
  */
 #ifndef SSW_AMD_H
 #define SSW_AMD_H

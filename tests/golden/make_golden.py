@@ -59,6 +59,27 @@ def config3(n_utts=4, n_frames=1000, n_phones=150):
     return res
 
 
+def config4(n_utts=32, n_frames=256):
+    """BASELINE configs[3] ("config 4"): the ms scorer on fr-fr, 8192 frames, with the
+    mixture_weights file the tests synthesise from the sendump (the ms scorer keeps no history:
+    one pass over all frames).  One CRC per 256-frame utterance and one over everything."""
+    import tempfile
+    from tests.test_cabi_host import synth_mixw_from_sendump
+    src = os.path.join(MODEL, "fr-fr")
+    ptm = O.Model(src)
+    with tempfile.TemporaryDirectory() as td:
+        mixw = os.path.join(td, "mixture_weights")
+        synth_mixw_from_sendump(ptm, mixw)
+        m = O.Model(mdef=os.path.join(src, "mdef"), means=os.path.join(src, "means"),
+                    vars=os.path.join(src, "variances"),
+                    tmat=os.path.join(src, "transition_matrices"), mixw=mixw)
+        means = read_raw_means(src)
+        feats = np.concatenate([synth_features(means, n_frames, 12345 + u) for u in range(n_utts)])
+        scr = m.ms_score_utt(feats)
+    return {"feats_crc": crc(feats), "crc": crc(scr),
+            "utt_crc": [crc(scr[u * n_frames:(u + 1) * n_frames]) for u in range(n_utts)]}
+
+
 def tables():
     """SURVEY 8(c) fixture 2: hashes of the post-load tables (load-time doubles go through libm,
     so the tables are data: a loader on another box must reproduce these bytes)."""
@@ -74,7 +95,8 @@ def tables():
 
 
 if __name__ == "__main__":
-    g = {"config2_en_us_ptm": config2(), "config3_align": config3(), "tables": tables()}
+    g = {"config2_en_us_ptm": config2(), "config3_align": config3(), "config4_fr_fr_ms": config4(),
+         "tables": tables()}
     with open(os.path.join(ROOT, "tests", "golden", "synthetic_oracle.json"), "w") as fh:
         json.dump(g, fh, indent=1)
     print(json.dumps(g)[:400])

@@ -30,6 +30,23 @@ def test_oracle_reproduces_golden_config2_sample(golden, orc_en, means_en):
     assert [crc(r) for r in scr[::64]] == g["frame_crc"][:4]
 
 
+def test_oracle_reproduces_golden_config4_sample(golden, oracle_mod, orc_fr, means_fr, tmp_path):
+    """The ms scorer's fixture (fr-fr, mixture_weights synthesised from the sendump): the first
+    two of its 32 utterances, recomputed by the oracle."""
+    from tests.conftest import MODEL_ROOT
+    from tests.test_cabi_host import synth_mixw_from_sendump
+    src = os.path.join(MODEL_ROOT, "fr-fr")
+    mixw = str(tmp_path / "mixture_weights")
+    synth_mixw_from_sendump(orc_fr, mixw)
+    o = oracle_mod.Model(mdef=os.path.join(src, "mdef"), means=os.path.join(src, "means"),
+                         vars=os.path.join(src, "variances"),
+                         tmat=os.path.join(src, "transition_matrices"), mixw=mixw)
+    g = golden["config4_fr_fr_ms"]
+    for u in range(2):
+        scr = o.ms_score_utt(synth_features(means_fr, 256, 12345 + u))
+        assert crc(scr) == g["utt_crc"][u]
+
+
 def test_oracle_reproduces_golden_alignment(golden, orc_en, means_en):
     g = golden["config3_align"][0]
     feats = synth_features(means_en, 1000, 12345)

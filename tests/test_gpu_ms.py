@@ -43,7 +43,17 @@ def test_ms_config4_8192_frames(ms_models, means_fr):
     got = g.score_batch(feats, off, scorer=ssw.SCORER_MS)
     flagged, pairs = g.last_stats()
     assert pairs == 8192 * 108
-    # the oracle needs ~1 ms per frame: check 1024 frames in full, the rest by invariants
+    # every one of the 8192 rows against the committed oracle checksums (tests/golden/
+    # make_golden.py:config4), and the first 1024 against the oracle run here
+    import json
+    import zlib
+    from tests.conftest import ROOT
+    with open(os.path.join(ROOT, "tests", "golden", "synthetic_oracle.json")) as fh:
+        gold = json.load(fh)["config4_fr_fr_ms"]
+    crc = lambda a: zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+    assert crc(feats) == gold["feats_crc"]
+    assert [crc(got[u * 256:(u + 1) * 256]) for u in range(32)] == gold["utt_crc"]
+    assert crc(got) == gold["crc"]
     ref = o.ms_score_utt(feats[:1024])
     assert np.array_equal(got[:1024], ref)
     assert (got.min(axis=1) == 0).all()
