@@ -26,7 +26,7 @@ def soak_align(a):
     t0 = time.time()
     n_utts = n_fail = bad = n_frames = 0
     while time.time() - t0 < a.seconds:
-        mode = ["mw", "reg", "lds"][n_utts % 3]
+        mode = ["mw", "reg", "lds", "hbm"][n_utts % 4]
         os.environ["SSW_ALIGN_KERNEL"] = mode
         k = int(rng.integers(1, 7))
         n_ph = rng.integers(1, 300, size=k).tolist()
