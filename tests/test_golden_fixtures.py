@@ -72,6 +72,22 @@ def test_gpu_matches_golden_config2_both_layouts(golden, gpu_en, means_en):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("knobs", [
+    {"SSW_SEN_FPB": "1"}, {"SSW_SEN_FPB": "4", "SSW_SEN_R": "2"}, {"SSW_SEN_FPB": "2", "SSW_SEN_R": "4"},
+    {"SSW_SEN_FPB": "4", "SSW_SEN_R": "3"}, {"SSW_MFMA_STEPS": "2"}, {"SSW_SCAN": "fma"},
+    {"SSW_SCAN": "fma", "SSW_SEN_FPB": "1", "SSW_SEN_R": "2"}])
+def test_tuning_knobs_do_not_change_results(golden, gpu_en, means_en, monkeypatch, knobs):
+    """the workgroup-shape and scan knobs are tuning aids -- config 2
+    (4096 frames) must give the committed checksums under every one of them."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    g = golden["config2_en_us_ptm"]["utt16x256"]
+    feats = np.concatenate([synth_features(means_en, 256, 12345 + u) for u in range(16)])
+    off = (np.arange(17) * 256).astype(np.int32)
+    assert crc(gpu_en.score_batch(feats, off)) == g["crc"]
+
+
+@pytest.mark.gpu
 def test_gpu_matches_golden_config3_alignment(golden, gpu_en, orc_en, means_en):
     """BASELINE config 3 shape (1000 frames, 150 phones), 4 utterances in one batch."""
     feats = np.concatenate([synth_features(means_en, 1000, 12345 + u) for u in range(4)])
