@@ -556,3 +556,36 @@ def test_a_page_of_2000_words(oracle_mod, gpu_en, orc_en):
                                     state_init=init)
     print(f"decoder_alignment of the page: {t3 - t2:.2f} s, {len(a['cipid'])} phones; oracle second pass {time.time() - t3:.2f} s")
     assert rv == 0 and np.array_equal(a["state_al"], rst)
+
+
+@pytest.mark.timeout(600)
+def test_long_and_short_texts_in_one_batch(oracle_mod, gpu_en, orc_en):
+    """A 700-word text (beyond the register kernel's 4096 HMMs and the LDS alignment kernel's
+    2,560 phones) between two short ones in ONE call: the batch goes through the HBM-resident
+    kernels as a whole, and every utterance must come out as when it is aligned alone."""
+    F, olex = _olex(oracle_mod, orc_en, "en-us")
+    lex = _lex(gpu_en, "en-us")
+    vocab = [w for w in olex.order[:olex.filler_start] if "(" not in w]
+    u = lcg_uniform(91, 720)
+    texts = [[vocab[int(x * len(vocab))] for x in u[:5]],
+             [vocab[int(x * len(vocab))] for x in u[10:710]],
+             [vocab[int(x * len(vocab))] for x in u[712:720]]]
+    assert len(lex.first_pass_graph(texts[1], max_nodes=1 << 17)[0]) > 4096
+    scores = [synth_scores(F, orc_en, olex, t, 70 + i, orc_en.n_sen, sil_p=0.1)
+              for i, t in enumerate(texts)]
+    off = np.concatenate([[0], np.cumsum([len(s) for s in scores])]).astype(np.int32)
+    d = torch.from_numpy(np.ascontiguousarray(np.concatenate(scores), np.int16)).cuda()
+    both = ssw.forced_align_batch(gpu_en, lex, d, off, texts)
+    for i in range(3):
+        assert both.status(i) == 0, i
+        a = both.utterance(i)
+        di = torch.from_numpy(np.ascontiguousarray(scores[i], np.int16)).cuda()
+        alone = ssw.forced_align_batch(gpu_en, lex, di, np.array([0, len(scores[i])], np.int32),
+                                       [texts[i]])
+        b = alone.utterance(0)
+        alone.free()
+        assert a["words"] == b["words"] and np.array_equal(a["state_al"], b["state_al"]), i
+        want = F.first_pass(orc_en, olex, texts[i], scores[i])
+        assert [w for (w, _, _, _) in want] == a["words"]
+    assert len(both.utterance(1)["cipid"]) > 2560
+    both.free()
