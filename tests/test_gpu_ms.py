@@ -59,6 +59,24 @@ def test_ms_config4_8192_frames(ms_models, means_fr):
     assert (got.min(axis=1) == 0).all()
 
 
+@pytest.mark.parametrize("knobs", [{"SSW_SEN_GENERIC": "1"}, {"SSW_SCAN": "fma"}])
+def test_ms_tuning_knobs_do_not_change_results(ms_models, means_fr, monkeypatch, knobs):
+    """The run-time-stream-count instance of ms_senone_kernel and the vector-unit scan give
+    config 4's committed checksums as well."""
+    import json
+    import zlib
+    from tests.conftest import ROOT
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    g, _ = ms_models
+    with open(os.path.join(ROOT, "tests", "golden", "synthetic_oracle.json")) as fh:
+        gold = json.load(fh)["config4_fr_fr_ms"]
+    feats = np.concatenate([synth_features(means_fr, 256, 12345 + i) for i in range(32)])
+    off = (np.arange(33) * 256).astype(np.int32)
+    got = g.score_batch(feats, off, scorer=ssw.SCORER_MS)
+    assert zlib.crc32(np.ascontiguousarray(got).tobytes()) & 0xFFFFFFFF == gold["crc"]
+
+
 def test_ms_exact_ties_take_the_exact_pass(ms_models, means_fr):
     """A frame sitting exactly on two identical densities is impossible to build from the model,
     but duplicated frames and extreme features must still agree with the oracle."""
