@@ -794,18 +794,38 @@ bf16_split3(float x, uint16_t p[3])
  * and X = (x, 1, x^2) are cut into three bf16 parts each and the six largest part products
  * (1,1) (1,2) (2,1) (2,2) (1,3) (3,1) are accumulated by v_mfma_f32_32x32x16_bf16 in fp32.
  * With u = 2^-24 and M = sum_k |W_k X_k| the key differs from the real number by at most
- *     u M (x^2 rounded) + 2 u M (residuals of the two splits) + 2 u M (the three part products
- *     left out) + 13 eps M (twelve chained MFMAs, each within eps of the exact sum of its
- *     products and its C input; eps <= 8 u: tools/microbench/mfma_bf16_scan.hip measures 4.3 u
- *     at worst on cancelling data, and tests/test_gpu_mfma_bound.py checks the resulting bound
- *     on the device) = 109 u M, taken as K u M with K = 119.
+ *     u M      x^2 rounded to fp32 before the split
+ *   + u M      residuals of the two splits (three round-to-nearest bf16 parts leave 2^-27) and
+ *              the three part products left out ((2,3) (3,2) (3,3): 2^-25 M together)
+ *   + the accumulation error of the twelve chained MFMAs.  Every product of two bf16 values is
+ *     exact in fp32, so MFMA i returns the exact sum of its 16 products and its C input up to
+ *     e_i <= eps (m_i + |C_i|), m_i = the sum of the |products| it adds.  The chain adds the
+ *     smallest products first: six MFMAs of (1,3) (3,1) (2,2) products (m_i <= 2^-16 M_kb), four
+ *     of (1,2) (2,1) products (m_i <= 2^-8 (1 + 2^-8) M_kb), then the (1,1) products of K block
+ *     0 and of K block 1 (m_i <= M_0, M_1; M_0 + M_1 = M).  |C_i| <= sum_{j<i} m_j (1 + eps)^i,
+ *     so  sum e_i <= eps sum_j m_j (1 + number of MFMAs after j)
+ *                 <= eps (12 * 3 * 2^-16 + 6 * 2 * 2^-8 * 1.004 + 2) M  <=  2.05 eps M:
+ *     only the last two MFMAs see terms of the size of M (round 2 charged all thirteen steps
+ *     with eps M and needed K = 119 for eps = 8 u).
+ * eps itself is not documented for v_mfma_f32_32x32x16_bf16.  Two models cover what a
+ * 17-term fp32 adder can do: (A) the terms are added one after the other, in any order, each
+ * addition rounded OR truncated to fp32: error <= 16 * 2^-23 = 32 u of sum |terms|; (B) the terms
+ * are aligned to the largest exponent, truncated to a 24-bit grid, summed exactly and rounded
+ * once: 16 * 2 u + 2 u = 34 u.  eps <= 34 u is assumed -- eight times the worst value
+ * tools/microbench/mfma_bf16_scan.hip measures on cancelling data (4.3 u), where round 2 had a
+ * factor below two -- which gives 2 u + 2.05 * 34 u = 71.7 u, taken as K u M with K = 80.
+ * tests/test_gpu_mfma_bound.py checks the resulting bound on the device on stress inputs and on
+ * inputs built to cancel (x = 2 mean: every a_j x_j + b_j x_j^2 pair cancels, M is 8 R while the
+ * value is det - R), and tests/test_gpu_scan_agreement.py that the matrix-core scan and the
+ * vector-unit scan (whose bound IS replayed on the CPU, tests/test_scan_bound.py) give
+ * identical top-N blocks.
  * The reference's own fp32 value is within 13 u |det| + 17 u S of the real number, and
  * M <= |det - d0| + 6 R + 3 S, S <= |det - d0| + |value - d0| as for recq, which gives the
  * per-density constant (4K + 17) |det - d0| + 6K R + 13 |det| folded into c below (with slack)
  * and the term (3K + 17) u |value - d0| the kernel adds to the one key it uses as a bound.
  * Densities whose constant exceeds SSW_MFMA_MAX_BIAS score units keep an inert record and are
  * evaluated in the exact form (exlistm). */
-#define SSW_MFMA_K 119.0
+#define SSW_MFMA_K 80.0
 #define SSW_MFMA_MAX_BIAS 64.0
 static int
 ssw_host_build_mfma_records(ssw_host_model_t *h)

@@ -12,7 +12,7 @@ from soundswallower_amd.synth import synth_features
 
 pytestmark = pytest.mark.gpu
 
-WIDEN = np.float32(2.2649765e-05)        # SSW_MFMA_WIDEN, csrc/ssw_k1a_mfma.inc
+WIDEN = np.float32(1.5676022e-05)        # SSW_MFMA_WIDEN, csrc/ssw_k1a_mfma.inc (K = 80)
 
 
 def _reference_densities(rec, x):
@@ -37,6 +37,35 @@ def _inputs(means, seed):
     return np.ascontiguousarray(np.concatenate(parts), np.float32)
 
 
+def _cancelling_rows(gpu, rec, d0):
+    """Inputs built against the accumulation, not drawn: for a density with mean m the key's
+    terms a_j x_j = 2 v_j m_j x_j and b_j x_j^2 = -v_j x_j^2 cancel pairwise at x = 2 m, where
+    M = sum |terms| is 8 R while the value is det - R -- the largest ratio of what the matrix
+    core adds up to what is left.  Taken at the densities with the largest R and the largest
+    |det - d0| of every stream, exactly on 2 m, a few ulps and a few per cent off it, with the
+    cancelling pairs in alternating dimensions only (half of the terms cancel, the others add),
+    and at x = m (value = det: the constant alone survives) and x = -2 m (nothing cancels)."""
+    n_cbf = rec.shape[0]
+    mean, var, det = rec[:, :, 0:13], rec[:, :, 16:29], rec[:, :, 15]
+    R = (var * mean * mean).sum(axis=2)
+    delta = np.abs(det - d0[:, None])
+    rows = []
+    for f in range(gpu.n_feat):
+        sel = np.arange(f, n_cbf, gpu.n_feat)
+        for score in (R[sel], delta[sel], (R * delta)[sel]):
+            for k in np.argsort(score.reshape(-1))[-10:]:
+                cbf, d = sel[int(k) // 128], int(k) % 128
+                m = mean[cbf, d]
+                alt = np.where(np.arange(13) % 2 == 0, 2.0, 0.5).astype(np.float32)
+                for x in (2 * m, np.nextafter(2 * m, np.float32(np.inf)), 2 * m * np.float32(1.03),
+                          m * alt, m * alt[::-1], m, -2 * m, 2 * m + np.float32(0.25)):
+                    row = np.zeros(39, np.float32)
+                    for g in range(gpu.n_feat):      # the other streams: the same construction
+                        row[g * 13:(g + 1) * 13] = x
+                    rows.append(row)
+    return np.ascontiguousarray(np.stack(rows), np.float32)
+
+
 @pytest.mark.parametrize("name", ["en-us", "fr-fr"])
 def test_mfma_keys_bound_the_reference_densities(gpu_en, gpu_fr, means_en, means_fr, name):
     gpu, means = (gpu_en, means_en) if name == "en-us" else (gpu_fr, means_fr)
@@ -53,7 +82,7 @@ def test_mfma_keys_bound_the_reference_densities(gpu_en, gpu_fr, means_en, means
         cbf, d = divmod(int(k), 128)
         f = cbf % gpu.n_feat
         rows[i, f * 13:(f + 1) * 13] = rec[cbf, d, 0:13]
-    feats = np.concatenate([feats, rows, rows * np.float32(1.0001)])
+    feats = np.concatenate([feats, rows, rows * np.float32(1.0001), _cancelling_rows(gpu, rec, d0)])
     worst = 0.0
     slack = []
     for cbf in range(n_cbf):
