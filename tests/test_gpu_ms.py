@@ -118,3 +118,33 @@ def test_ms_mgau_vtable_compallsen_no(ms_models, means_fr, oracle_mod):
         ref = o.ms_frame_eval(feats[t], t, compallsen=False, senone_active=lst)
         assert np.array_equal(got, ref), t
     mg.free()
+
+
+def test_ms_packed_senone_kernel_and_its_marked_frames(ms_models, means_fr, monkeypatch):
+    """Round 3: batches of the ms scorer go through the packed persistent senone kernel (the PTM
+    kernel's machinery, 16 bits per slot).  What 16 bits cannot hold -- a density at or below
+    logmath's zero, where logmath_add's short-cuts apply (src/logmath.c:228-272), or sums beyond
+    int16, where src/ms_mgau.c:314-320 clamps -- marks the frame, and marked frames are redone
+    with the reference's own arithmetic.  Features scaled by 100 .. 3000 put densities below
+    -5.4e8 (zero << 10) and below -2^31 (the clamp of src/ms_senone.c:332-335); they are mixed
+    with ordinary frames so that marked and unmarked frames share units.  Against the oracle and
+    against ms_senone_kernel (SSW_MS_SENONE=old), frame by frame."""
+    g, o = ms_models
+    rng = np.random.default_rng(5)
+    base = synth_features(means_fr, 2560, 321)
+    scale = np.ones(len(base), np.float32)
+    pick = rng.random(len(base)) < 0.08
+    scale[pick] = rng.choice(np.array([100.0, 300.0, 1000.0, 3000.0, 30.0], np.float32), int(pick.sum()))
+    feats = np.ascontiguousarray(base * scale[:, None], np.float32)
+    feats[7] = 0.0
+    got = g.score_batch(feats, scorer=ssw.SCORER_MS)
+    monkeypatch.setenv("SSW_MS_SENONE", "old")
+    old = g.score_batch(feats, scorer=ssw.SCORER_MS)
+    monkeypatch.delenv("SSW_MS_SENONE")
+    bad = np.nonzero((got != old).any(axis=1))[0]
+    assert len(bad) == 0, (bad[:10], scale[bad[:10]])
+    ref = o.ms_score_utt(feats[:400])
+    assert np.array_equal(got[:400], ref)
+    sel = np.nonzero(pick)[0][:40]
+    for t in sel:                       # the extreme frames one by one against the oracle
+        assert np.array_equal(got[t], o.ms_score_utt(feats[t:t + 1])[0]), (t, scale[t])
