@@ -20,7 +20,8 @@ Prints ONE JSON line on rank 0, including
                  gather_ms and a CRC of the gathered alignments that does not depend on N;
   `batch_65536`, `real_features`, `align`, `text_align`  (N = 1 only) the same scoring step
                  at 65,536 frames, on features of a real recording, and BASELINE configs[2]
-                 from phone strings and from text.
+                 from phone strings and from text;
+  `config4`      (N = 1 only) BASELINE configs[3]: the ms scorer on fr-fr, 8192 frames per step.
 """
 from __future__ import annotations
 
@@ -41,7 +42,7 @@ UTT_FRAMES = 256
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, MI355X_MICROARCH.md
 N_SIMD = 1024                   # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9
-PMC_FILE = "r02_pmc.json"      # rocprofv3 --pmc passes of this step (tools/pmc_pass.py); only
+PMC_FILE = "r03_pmc.json"      # rocprofv3 --pmc passes of this step (tools/pmc_pass.py); only
                                # quoted when its kernel_src_sha equals this tree's
 
 
@@ -390,6 +391,9 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
+        "scaling_note": "value = weak scaling of the scoring step (4096 frames per rank, no "
+                        "data-path collective); config5 = the STRONG-scaling job of BASELINE "
+                        "configs[4] (2048 utterances dealt over the ranks, one gather)",
         "vs_baseline": None,
         "dtype": "f32+i32",
         "data": "synthetic",
@@ -398,7 +402,10 @@ def main():
                                f"39-dim features resident in HBM, compallsen=yes, topn=4",
                    "senones": model.n_sen, "codebooks": model.n_cb,
                    "parallelism": f"utt-shard x{world}"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # `bound`: what the measured counters say binds (vector-instruction issue, see valu_frac);
+        # achieved / peak / frac stay the touched-bytes figure against the HBM peak, the number
+        # north_star and SURVEY 8(d) grade
+        "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_source,
                      "kernel": "PTM path of one step: ptm_topn_mfma (or ptm_topn_frames, SSW_SCAN=fma) "
@@ -410,9 +417,9 @@ def main():
                              "weight table, which L2 serves; the path is VALU-issue bound "
                              "(DESIGN.md section 5): see valu_frac"},
         "kernels": per_kernel,
-        # share of the VALU issue slots the step uses if every wave64 instruction took the
-        # nominal 4 cycles (SQ_INSTS_VALU from the PMC file); add/sub/mul/fma/logic issue in 2 on
-        # gfx950 (tools/microbench/valu_rate.hip), so this over-counts the senone kernel
+        # share of the SIMDs' vector issue slots the step uses at 4 cycles per wave64 instruction
+        # (SQ_INSTS_VALU from the PMC file), at the nominal 2.4 GHz (the chip holds less under
+        # this load, so the true share is higher)
         "valu_frac": (valu_instr * 4.0 / N_SIMD / CLOCK_HZ / (path_ms * 1e-3)
                       if valu_instr else None),
         "exact_pass_share": flagged / max(pairs, 1),
@@ -446,6 +453,14 @@ def main():
         import bench_first_pass
         lex = ssw.Lexicon(model, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
         out["text_align"] = bench_first_pass.run(ssw, model, lex, torch)
+    if world == 1 and not args.no_extra:
+        # BASELINE configs[3]: the ms scorer (ms_gauden + ms_senone kernels), fr-fr, 8192 frames
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import bench_ms
+        try:
+            out["config4"] = bench_ms.run()
+        except Exception as e:      # noqa: BLE001 -- the headline line must still come out
+            out["config4"] = {"error": str(e)}
     if cpu is not None:
         out["cpu_baseline"] = cpu
     print(json.dumps(out), flush=True)

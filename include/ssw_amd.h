@@ -456,6 +456,12 @@ ssw_comm_t *ssw_comm_init(const char id[SSW_COMM_ID_BYTES], int32_t n_ranks, int
                           int32_t device);
 /* wrap a communicator the host already has (an ncclComm_t); not destroyed by ssw_comm_free */
 ssw_comm_t *ssw_comm_from_nccl(void *nccl_comm, int32_t n_ranks, int32_t rank, int32_t device);
+/* A host with a transport of its own (MPI_Allgather, a test double): `fn` must deliver, on
+ * every rank, the n_int32_per_rank words each rank passes in `send` to recv[r * n_int32_per_rank
+ * ..] for r = 0 .. n_ranks - 1 (host memory on both sides) and return 0.  ssw_gather_alignments
+ * then pads, exchanges and unpacks through it without touching RCCL or HIP. */
+typedef int (*ssw_all_gather_fn)(void *ctx, const void *send, void *recv, size_t n_int32_per_rank);
+ssw_comm_t *ssw_comm_from_transport(ssw_all_gather_fn fn, void *ctx, int32_t n_ranks, int32_t rank);
 void ssw_comm_free(ssw_comm_t *c);
 /* Collective.  local: this rank's n_local entries (the state entries of its utterances, in its
  * shard's order); counts [n_ranks]: entries of every rank -- known to all of them, being a

@@ -183,6 +183,8 @@ def lib() -> C.CDLL:
     L.ssw_comm_init.argtypes = [C.c_char_p, i32, i32, i32]
     L.ssw_comm_from_nccl.restype = vp
     L.ssw_comm_from_nccl.argtypes = [vp, i32, i32, i32]
+    L.ssw_comm_from_transport.restype = vp
+    L.ssw_comm_from_transport.argtypes = [vp, vp, i32, i32]
     L.ssw_comm_free.argtypes = [vp]
     L.ssw_comm_free.restype = None
     L.ssw_gather_alignments.argtypes = [vp, vp, i32, vp, vp, vp]

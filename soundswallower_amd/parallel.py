@@ -34,15 +34,23 @@ class RcclComm:
 
         from . import _lib
         self._L = _lib.lib()
+        self._c = None
         buf = C.create_string_buffer(128)
+        # Rank 0 draws the id.  A failure there must not leave the other ranks waiting in the
+        # broadcast: the status byte travels WITH the id and every rank raises after
+        # the collective.
+        status, err = 0, ""
         if rank == 0 and self._L.ssw_comm_unique_id(buf) < 0:
-            raise RuntimeError("ssw_comm_unique_id: " + _lib.last_error())
-        t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            status, err = 1, _lib.last_error()
+        t = torch.frombuffer(bytearray(bytes([status]) + buf.raw), dtype=torch.uint8).clone()
         if world_size > 1:
             backend = dist.get_backend()
             t = t.to(torch.device("cuda", device_index)) if backend == "nccl" else t
             dist.broadcast(t, src=0)
-        idb = bytes(t.cpu().numpy().tobytes())
+        raw = bytes(t.cpu().numpy().tobytes())
+        if raw[0] != 0:
+            raise RuntimeError("ssw_comm_unique_id failed on rank 0" + (": " + err if err else ""))
+        idb = raw[1:]
         self._c = self._L.ssw_comm_init(idb, world_size, rank, device_index)
         if not self._c:
             raise RuntimeError("ssw_comm_init: " + _lib.last_error())
@@ -66,6 +74,35 @@ class RcclComm:
             self._c = None
 
     __del__ = close
+
+
+class TransportComm(RcclComm):
+    """ssw_comm_from_transport: the same C gather (padding, exchange, unpacking) over an
+    all-gather the HOST supplies -- what an MPI host passes (MPI_Allgather), and the seam the CPU
+    tests drive ssw_gather_alignments through with several ranks.  `all_gather(send, recv,
+    n_int32_per_rank)` gets two int32 numpy views (recv [world_size][n_int32_per_rank])."""
+
+    def __init__(self, all_gather, world_size: int, rank: int):
+        import ctypes as C
+
+        from . import _lib
+        self._L = _lib.lib()
+        self.world_size, self.rank = world_size, rank
+
+        def thunk(_ctx, send, recv, n):
+            try:
+                s = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_int32)), shape=(int(n),))
+                r = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_int32)),
+                                          shape=(world_size, int(n)))
+                all_gather(s, r, int(n))
+                return 0
+            except Exception:      # noqa: BLE001 -- reported through the C error path
+                return 1
+
+        self._fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)(thunk)
+        self._c = self._L.ssw_comm_from_transport(C.cast(self._fn, C.c_void_p), None, world_size, rank)
+        if not self._c:
+            raise RuntimeError("ssw_comm_from_transport: " + _lib.last_error())
 
 
 def gather_alignments(local_states, n_states_per_utt, world_size: int, rank: int, *,

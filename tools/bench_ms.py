@@ -29,42 +29,46 @@ def write_s3(path, payload):
         fh.write(hdr + struct.pack("<I", 0x11223344) + payload + struct.pack("<I", s))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--utts", type=int, default=32)
-    ap.add_argument("--frames", type=int, default=256)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    a = ap.parse_args()
+MS_BYTES_PER_FRAME = 29850.0   # SURVEY 8(d) touched bytes per frame of config 4 (fr-fr, ms scorer)
+
+
+def build_model(tmpdir=None):
+    """fr-fr with a mixture_weights file synthesised from its sendump; returns (model, means)."""
     _lib.build()
-    L = _lib.lib()
     mdir = ssw.model_dir("fr-fr")
     tables = ssw.Model(mdir, config={"device": -2})
     q = tables.table("ptm_mixw").reshape(tables.n_feat, tables.n_density, tables.n_sen)
     pdf = np.ascontiguousarray(np.power(1.0001, -(q.astype(np.float64) * 1024.0)).transpose(2, 0, 1),
                                dtype="<f4")
-    tmp = tempfile.mkdtemp()
+    tmp = tmpdir or tempfile.mkdtemp()
     mixw = os.path.join(tmp, "mixture_weights")
     write_s3(mixw, struct.pack("<4i", pdf.shape[0], pdf.shape[1], pdf.shape[2], pdf.size)
              + pdf.tobytes())
     m = ssw.Model(mdef=os.path.join(mdir, "mdef"), means=os.path.join(mdir, "means"),
                   variances=os.path.join(mdir, "variances"),
                   tmat=os.path.join(mdir, "transition_matrices"), mixw=mixw)
-    means = read_raw_means(mdir)
-    feats = np.concatenate([synth_features(means, a.frames, 4242 + u) for u in range(a.utts)])
+    return m, read_raw_means(mdir)
+
+
+def run(utts=32, frames=256, steps=100, warmup=10):
+    """BASELINE configs[3]: `steps` back-to-back ssw_score_batch(SSW_SCORER_MS) calls over one
+    resident batch; returns the dict bench.py puts under `config4`."""
+    L = _lib.lib()
+    m, means = build_model()
+    feats = np.concatenate([synth_features(means, frames, 4242 + u) for u in range(utts)])
     n = feats.shape[0]
-    off = (np.arange(a.utts + 1) * a.frames).astype(np.int32)
+    off = (np.arange(utts + 1) * frames).astype(np.int32)
     d_feats = m.to_device(feats)
     d_out = L.ssw_device_malloc(n * m.n_sen * 2)
 
     def step():
         m.score_batch_device(d_feats, n, off, d_out, scorer=ssw.SCORER_MS)
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     L.ssw_device_synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step()
     L.ssw_device_synchronize()
     dt = time.perf_counter() - t0
@@ -74,13 +78,33 @@ def main():
         step()
         k += np.array(m.kernel_timing())
     k /= 20
+    m.set_kernel_timing(False)
     flagged, pairs = m.last_stats()
-    print(json.dumps({
-        "workload": f"ms scorer (ms_gauden + ms_senone), fr-fr, {a.utts} x {a.frames} = {n} frames per step",
-        "frames_per_s": n * a.steps / dt, "ms_per_step": dt / a.steps * 1e3,
+    m.device_free(d_feats)
+    L.ssw_device_free(d_out)
+    ms = dt / steps * 1e3
+    return {
+        "workload": f"ms scorer (ms_gauden + ms_senone), fr-fr, {utts} x {frames} = {n} frames per "
+                    f"step, mixture_weights synthesised from the sendump (BASELINE configs[3])",
+        "frames_per_s": n * steps / dt, "ms_per_step": ms,
         "topn_kernels_ms": float(k[0]), "senone_kernel_ms": float(k[1]),
+        "kernel_ms": float(k.sum()),
+        "algorithmic_bytes_per_frame": MS_BYTES_PER_FRAME,
+        # touched-bytes GB/s over the HBM peak, on the wall time and on the kernels' own time
+        "roofline_frac": MS_BYTES_PER_FRAME * n / (ms * 1e-3) / 1e9 / 8000.0,
+        "roofline_frac_kernels": MS_BYTES_PER_FRAME * n / (float(k.sum()) * 1e-3) / 1e9 / 8000.0,
         "exact_pass_share": flagged / max(pairs, 1),
-        "n_sen": m.n_sen, "n_cb": m.n_cb, "n_density": m.n_density}))
+        "n_sen": m.n_sen, "n_cb": m.n_cb, "n_density": m.n_density}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--utts", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    a = ap.parse_args()
+    print(json.dumps(run(a.utts, a.frames, a.steps, a.warmup)))
 
 
 if __name__ == "__main__":
