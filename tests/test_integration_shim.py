@@ -1,7 +1,14 @@
-"""The reference-side binding of INTEGRATION.md compiles against SoundSwallower's own public
-headers, and the layout claims of include/ssw_amd.h (ssw_mgau_t / ssw_mgaufuncs_t mirror mgau_t /
-mgaufuncs_t member for member) hold as _Static_asserts.  Needs the reference's include/ tree,
-which exists in the development container only."""
+"""The reference-side binding of INTEGRATION.md (examples/integration_shim.c).
+
+(i) It compiles against SoundSwallower's own public headers, and the layout claims of
+include/ssw_amd.h (ssw_mgau_t / ssw_mgaufuncs_t mirror mgau_t / mgaufuncs_t member for member)
+hold as _Static_asserts.
+(ii) Round 3: it is LINKED with the real reference library and RUN.  The test
+configures and builds /root/reference out of tree in a scratch directory (cmake generates the
+config.h the sources include; nothing is written to the reference or to this repository), links
+the shim with tests/harness/ssw_amd_stub.c in place of libssw_amd.so (no GPU here) and drives
+decoder_alignment through it on the reference's own test recording: tests/harness/shim_driver.c.
+Both need the reference tree, which exists in the development container only."""
 import os
 import subprocess
 
@@ -18,3 +25,43 @@ def test_integration_shim_compiles_against_reference_headers():
            "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "integration_shim.c")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def _have(tool):
+    import shutil
+    return shutil.which(tool) is not None
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src") or not _have("cmake"),
+                    reason="needs the reference sources and cmake (development container)")
+def test_shim_linked_with_the_reference_and_run(tmp_path):
+    """decoder_alignment (src/decoder.c:737-798) driving the shim's search module and the
+    reference calling the shim's scorer object through its own mgau_t / mgaufuncs_t view -- see
+    tests/harness/shim_driver.c for the three runs and what each proves.  Under ASan + UBSan with
+    leak detection: the consuming free order of gpu_sas_free (search_module_base_free, the GPU
+    object, the alignment) and the scorer's free slot are exercised by the reference itself."""
+    ref = tmp_path / "ref"
+    ref.mkdir()
+    for cmd in (["cmake", "-S", "/root/reference", "-B", str(ref), "-DCMAKE_BUILD_TYPE=Release",
+                 "-DBUILD_TESTING=OFF"],
+                ["cmake", "--build", str(ref), "--target", "soundswallower", "-j", "8"]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    drv = str(tmp_path / "shim_driver")
+    h = os.path.join(ROOT, "tests", "harness")
+    cmd = ["gcc", "-g", "-O1", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+           "-std=gnu99", "-Wall", "-Werror", "-I" + REF_INC, "-I" + str(ref),
+           "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "integration_shim.c"),
+           os.path.join(h, "ssw_amd_stub.c"), os.path.join(h, "shim_driver.c"),
+           str(ref / "libsoundswallower.a"), "-lm", "-Wl,--wrap=state_align_search_init", "-o", drv]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([drv, os.path.join(ROOT, "soundswallower_amd", "model", "en-us"),
+                        os.path.join(ROOT, "tests", "golden", "goforward.raw")],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    assert "SHIM-DRIVER OK: 6 words, 18 phones, 54 states over 278 frames" in r.stdout
+    assert "ERROR" not in r.stderr
