@@ -123,6 +123,11 @@ int ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_
  *              call synchronous) -- pass it as carry_in of the next call / the second pass.
  * The ms scorer keeps no history: the three are ignored for it. */
 #define SSW_SCORE_CARRY_UTTS 1u
+/* the caller runs kernels of ANOTHER stream beside this call (the alignment of the previous
+ * chunk beside the scoring of the next, section "Multi-GPU" / soundswallower_amd/jobs.py): the
+ * persistent scoring workgroups then leave after 8 frame pairs instead of staying for the
+ * whole batch, so the other stream finds free wave slots every ~100 us.  Same results. */
+#define SSW_SCORE_SHARE_DEVICE 2u
 int ssw_score_batch_ex(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_frames,
                        const int32_t *utt_off, int32_t n_utts, int16_t *d_out, void *stream,
                        uint32_t flags, const uint32_t *carry_in, uint32_t *carry_out);

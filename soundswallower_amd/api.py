@@ -136,12 +136,18 @@ class Model:
         return out
 
     def score_batch_device(self, d_feats, n_frames, utt_off, d_out, stream=None,
-                           scorer=SCORER_PTM):
-        """Device pointers (ints or torch tensors); asynchronous on `stream`."""
+                           scorer=SCORER_PTM, share_device=False):
+        """Device pointers (ints or torch tensors); asynchronous on `stream`.  share_device:
+        SSW_SCORE_SHARE_DEVICE, for callers that run another stream's kernels beside it."""
         off = np.ascontiguousarray(utt_off, np.int32)
+        st = C.c_void_p(int(stream)) if stream else None
+        if share_device:
+            _check(self._L.ssw_score_batch_ex(self._m, scorer, _ptr(d_feats), int(n_frames),
+                                              _ptr(off), len(off) - 1, _ptr(d_out), st, 2, None,
+                                              None), "ssw_score_batch_ex")
+            return
         _check(self._L.ssw_score_batch(self._m, scorer, _ptr(d_feats), int(n_frames), _ptr(off),
-                                       len(off) - 1, _ptr(d_out),
-                                       C.c_void_p(int(stream)) if stream else None),
+                                       len(off) - 1, _ptr(d_out), st),
                "ssw_score_batch")
 
     def score_batch_carry(self, feats, utt_off=None, carry_in=None, carry_utts=False,

@@ -95,7 +95,7 @@ class Config5Shard:
             n = c1 - c0
             frame_off = (np.arange(n + 1) * F).astype(np.int32)
             m.score_batch_device(self.d_feats + c0 * F * row, n * F, frame_off, self.d_scr2[k & 1],
-                                 self.s_score)
+                                 self.s_score, share_device=True)
 
         launch_score(0)
         for k, (c0, c1) in enumerate(chunks):
