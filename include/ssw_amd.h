@@ -306,6 +306,12 @@ typedef struct ssw_first_pass_config_s {
     float silprob, fillprob;   /* 0.005, 1e-8 */
     int32_t use_filler;        /* fsgusefiller, 1 */
     int32_t use_altpron;       /* fsgusealtpron, 1 */
+    /* ssw_align_text_batch only, PTM scorer: score the second pass as decoder_alignment does
+     * (src/decoder.c:786-793, src/ptm_mgau.c:425-448) -- again, after the rewind, every
+     * utterance starting from the top-N history its own first pass left -- instead of feeding
+     * both passes with the scores made from the reset history.  The two differ only where
+     * truncated densities tie; costs a second scoring pass.  0 by default. */
+    int32_t two_pass_history;
 } ssw_first_pass_config_t;
 void ssw_first_pass_config_defaults(ssw_first_pass_config_t *cfg);
 

@@ -39,7 +39,7 @@ class FirstPassConfig(C.Structure):
     _fields_ = [("beam", C.c_double), ("pbeam", C.c_double), ("wbeam", C.c_double),
                 ("wip", C.c_double), ("pip", C.c_double), ("lw", C.c_float),
                 ("silprob", C.c_float), ("fillprob", C.c_float), ("use_filler", C.c_int32),
-                ("use_altpron", C.c_int32)]
+                ("use_altpron", C.c_int32), ("two_pass_history", C.c_int32)]
 
 
 FP_NODE_DTYPE = np.dtype([("senid", np.uint16, 3), ("tmat", np.int16), ("pen", np.int32),
