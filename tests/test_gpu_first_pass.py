@@ -505,6 +505,17 @@ def test_hbm_resident_kernel_equals_the_register_one(oracle_mod, gpu_en, gpu_fr,
     bigf = _first_pass(gpu_fr, lexf, scoresf, textsf)
     assert big == small and bigf == smallf
     assert sum(g is not None for g in big) >= 12 and all(g is not None for g in bigf)
+    # round 3: the kernel walks a band of grammar states and keeps a banded history table; without
+    # the band (SSW_FP_BAND=0) and with a history budget so small that it overflows and the batch
+    # falls back to the full table (SSW_FP_HIST_BAND=1) the result is the same
+    monkeypatch.setenv("SSW_FP_BAND", "0")
+    assert _first_pass(gpu_en, lex, scores, texts) == small
+    assert _first_pass(gpu_fr, lexf, scoresf, textsf) == smallf
+    monkeypatch.delenv("SSW_FP_BAND")
+    monkeypatch.setenv("SSW_FP_HIST_BAND", "1")
+    assert _first_pass(gpu_en, lex, scores, texts) == small
+    assert _first_pass(gpu_fr, lexf, scoresf, textsf) == smallf
+    monkeypatch.delenv("SSW_FP_HIST_BAND")
     for t in range(0, 24, 5):
         want = F.first_pass(orc_en, olex, texts[t], scores[t])
         assert (want is None and big[t] is None) or \
