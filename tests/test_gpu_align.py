@@ -159,9 +159,29 @@ def test_utterance_beyond_the_lds_limit(gpu_en, orc_en):
         # ... and without windows: every phone from 0 to the frontier stays in the walked range
         rv2, rst2, _ = orc_en.state_align(scr[:7000], senid[:2600], tmat[:2600])
         st2, status2 = gpu_en.align_batch(d, [0, 7000], [0, 2600], senid[:2600], tmat[:2600])
+        # round 3: the token table of this kernel is banded (the walked 64-phone words of every
+        # frame only).  The full [frame][state] table (SSW_ALIGN_BAND=0) and a budget so small
+        # that the bands overflow it and the call falls back to the full table
+        # (SSW_ALIGN_BAND_TOKENS=192: one word per frame) must give the same entries.
+        import os
+        variants = []
+        for env in ({"SSW_ALIGN_BAND": "0"}, {"SSW_ALIGN_BAND_TOKENS": "192"}):
+            os.environ.update(env)
+            try:
+                variants.append(gpu_en.align_batch(d, [0, n_frames], [0, n_phones], senid, tmat,
+                                                   sf=sf, ef=ef))
+                variants.append(gpu_en.align_batch(d, [0, 7000], [0, 2600], senid[:2600], tmat[:2600]))
+            finally:
+                for k in env:
+                    del os.environ[k]
     finally:
         gpu_en.device_free(d)
     assert rv == 0 and status[0] == 0 and np.array_equal(st, rst)
     assert (status2[0] == 0) == (rv2 == 0)
     if rv2 == 0:
         assert np.array_equal(st2, rst2)
+    for k, (stv, statusv) in enumerate(variants):
+        want_st, want_status = (st, status) if k % 2 == 0 else (st2, status2)
+        assert statusv[0] == want_status[0], k
+        if want_status[0] == 0:
+            assert np.array_equal(stv, want_st), k
