@@ -15,7 +15,17 @@
  * offsets, the score rows of ssw_align_text_batch): one call at a time per model, from any
  * thread; calls on different models -- one per host thread or per stream of work -- run side by
  * side.  Host-only calls (ssw_first_pass_prepare, ssw_alignment_populate, the dictionary and JSON
- * functions) only read the model and may run beside a device call on it.
+ * functions) only read the model and may run beside a device call on it.  The rule is enforced:
+ * a compute call that finds another thread inside one on the same model fails with "the model is
+ * in use by another thread" instead of sharing its workspaces.
+ *
+ * Inputs: parity with the reference is claimed for FINITE features.  A NaN or infinity in a
+ * feature row is not refused (checking every row would cost a pass over the batch): every
+ * (codebook, stream) pair it touches fails the scan's proof test and is scored by the exact
+ * in-wave pass, whose float -> int conversions then follow the GPU's rules (saturating, NaN ->
+ * 0) where the reference's `(int32)` casts follow the host CPU's (x86: 0x80000000) -- the
+ * scores of such a frame are defined, but not the reference's.  Hosts that cannot rule
+ * non-finite cepstra out should screen them before ssw_feat_batch / ssw_score_batch.
  */
 #ifndef SSW_AMD_H
 #define SSW_AMD_H

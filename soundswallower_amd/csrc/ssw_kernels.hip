@@ -34,6 +34,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <functional>
 #include <chrono>
 #include <climits>
 #include <cmath>

@@ -298,3 +298,40 @@ def test_second_pass_scores_from_the_batch_api(oracle_mod, orc_en, gpu_en):
     ref_second = two_pass_scores(orc_en, feats)
     assert np.array_equal(first, ref_first)
     assert np.array_equal(second, ref_second)
+
+
+def test_a_model_refuses_a_second_thread(gpu_en, means_en):
+    """include/ssw_amd.h, Threading: an ssw_model_t is not re-entrant; round 3 enforces it.  While
+    one thread scores large batches another thread's calls on the SAME model fail with "in use by
+    another thread" (and never corrupt the first thread's results); on a model of its own the
+    second thread works."""
+    import threading
+    feats = np.concatenate([synth_features(means_en, 256, 9000 + u) for u in range(128)])
+    off = (np.arange(129) * 256).astype(np.int32)
+    want = gpu_en.score_batch(feats, off)
+    stop, refused, other_ok = threading.Event(), [], []
+
+    def intruder():
+        small = synth_features(means_en, 40, 1)
+        while not stop.is_set():
+            try:
+                gpu_en.score_batch(small)
+                other_ok.append(1)
+            except ssw.SswError as e:
+                refused.append(str(e))
+
+    th = threading.Thread(target=intruder)
+    th.start()
+    try:
+        for _ in range(6):
+            got = gpu_en.score_batch(feats, off)      # a refusal of THIS thread would raise here
+            assert np.array_equal(got, want)
+    except ssw.SswError as e:                          # the intruder got in first: legitimate,
+        assert "another thread" in str(e)              # the rule cuts both ways
+    finally:
+        stop.set()
+        th.join()
+    assert refused and all("another thread" in r for r in refused), (len(refused), len(other_ok))
+    mine = ssw.Model(ssw.model_dir("en-us"))
+    assert np.array_equal(mine.score_batch(feats[:256]), want[:256])
+    mine.close()
