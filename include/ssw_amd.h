@@ -235,6 +235,18 @@ int ssw_align_batch_active(ssw_model_t *m, const float *d_feats, int32_t n_utts,
                            const int32_t *ef, const uint32_t *seed_active,
                            ssw_align_entry_t *state_io, int32_t *status, int16_t *d_senscr,
                            void *stream);
+/* The same with the scorer named (round 3): SSW_SCORER_MS follows ms_cont_mgau_frame_eval's
+ * active-list half (src/ms_mgau.c:322-365): only the listed senones are evaluated and written,
+ * normalised by the best of them with the int16 clamp (bridge entries of the delta list are
+ * listed entries).  d_senscr rows hold 0 wherever the frame's list has no entry: acmod's buffer
+ * would still show the last value of an entry that has dropped out of the list -- only bridge
+ * entries ever do, when a senone between their neighbours joins the set, and no HMM reads them. */
+int ssw_align_batch_active_ex(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_utts,
+                              const int32_t *frame_off, const int32_t *phone_off,
+                              const uint16_t *senid, const int16_t *tmatid, const int32_t *sf,
+                              const int32_t *ef, const uint32_t *seed_active,
+                              ssw_align_entry_t *state_io, int32_t *status, int16_t *d_senscr,
+                              void *stream);
 /* alignment_propagate (src/ps_alignment.c:316-352): sums children into parents.
  * parent[i] = index of child i's parent; parents must appear in non-decreasing order. */
 int ssw_alignment_propagate(const ssw_align_entry_t *child, const int32_t *parent,

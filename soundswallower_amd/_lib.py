@@ -109,6 +109,7 @@ def lib() -> C.CDLL:
     L.ssw_mgau_prescore.argtypes = [C.POINTER(SswMgau), vp, i32]
     L.ssw_align_batch.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.ssw_align_batch_active.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ssw_align_batch_active_ex.argtypes = [vp, C.c_int, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.ssw_alignment_propagate.argtypes = [vp, vp, i32, vp, i32]
     L.ssw_state_align_search_init.restype = vp
     L.ssw_state_align_search_init.argtypes = [vp, C.POINTER(SswMgau), i32, vp, vp, vp, vp]

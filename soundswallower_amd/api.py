@@ -234,7 +234,8 @@ class Model:
         return states, status
 
     def align_batch_active(self, d_feats, frame_off, phone_off, senid, tmatid, sf=None, ef=None,
-                           seed_active=None, state_init=None, d_senscr=None, stream=None):
+                           seed_active=None, state_init=None, d_senscr=None, stream=None,
+                           scorer=SCORER_PTM):
         """ssw_align_batch_active: scoring over the search's active senones (compallsen = no) +
         forced alignment; returns (states[n,3] int32, status[n_utts])."""
         frame_off = np.ascontiguousarray(frame_off, np.int32)
@@ -250,8 +251,8 @@ class Model:
         n_utts = len(frame_off) - 1
         status = np.zeros(n_utts, np.int32)
         seed = None if seed_active is None else np.ascontiguousarray(seed_active, np.uint32)
-        _check(self._L.ssw_align_batch_active(
-            self._m, _ptr(d_feats), n_utts, _ptr(frame_off), _ptr(phone_off), _ptr(senid),
+        _check(self._L.ssw_align_batch_active_ex(
+            self._m, int(scorer), _ptr(d_feats), n_utts, _ptr(frame_off), _ptr(phone_off), _ptr(senid),
             _ptr(tmatid), _ptr(sf), _ptr(ef), _ptr(seed), _ptr(states), _ptr(status),
             _ptr(d_senscr), C.c_void_p(int(stream)) if stream else None),
             "ssw_align_batch_active")
