@@ -163,6 +163,11 @@ int ssw_score_batch_stats(ssw_model_t *m, int64_t stats[2]);
  * ms[0] = top-N (density) kernel(s), ms[1] = senone kernel.  Returns the number written. */
 int ssw_set_kernel_timing(ssw_model_t *m, int enable);
 int ssw_get_kernel_timing(ssw_model_t *m, float *ms, int n);
+/* measurement aid: `reps` ssw_score_batch calls on the same batch back to back, then one
+ * synchronise (tools/bench_frame_sync.py) */
+int ssw_debug_score_loop(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_frames,
+                         const int32_t *utt_off, int32_t n_utts, int16_t *d_out, int32_t reps,
+                         void *stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* Scorer object: drop-in for mgau_t / mgaufuncs_t (include/soundswallower/acmod.h:93-111).*/

@@ -94,6 +94,7 @@ def lib() -> C.CDLL:
     L.ssw_model_table.restype = vp
     L.ssw_model_table.argtypes = [vp, C.c_int, C.POINTER(sz)]
     L.ssw_score_batch.argtypes = [vp, C.c_int, vp, i32, vp, i32, vp, vp]
+    L.ssw_debug_score_loop.argtypes = [vp, C.c_int, vp, i32, vp, i32, vp, i32, vp]
     L.ssw_score_batch_ex.argtypes = [vp, C.c_int, vp, i32, vp, i32, vp, vp, C.c_uint32, vp, vp]
     L.ssw_score_batch_host.argtypes = [vp, C.c_int, vp, i32, vp, i32, vp]
     L.ssw_score_batch_topn.argtypes = [vp, i32, vp, vp]
