@@ -31,12 +31,12 @@ class Config5Shard:
         self.model, self.rank, self.world = model, rank, world
         self.n_utts, self.n_frames, self.n_phones = n_utts, n_frames, n_phones
         self.mine = shard_utterances([n_frames] * n_utts, world)[rank]
-        # Scoring runs a chunk ahead of alignment (score_and_align), which only pays with several
-        # chunks per rank: at 8 ranks a shard of 256 utterances would be ONE chunk of 256 and the
-        # overlap would be gone.  At least 4 chunks per rank, never below 32
-        # utterances (32,000 frames per scoring launch still fills the chip).
-        quarter = -(-max(1, len(self.mine)) // 4)
-        self.chunk_utts = max(1, min(chunk_utts, max(32, quarter), max(1, len(self.mine))))
+        # Scoring runs a chunk ahead of alignment (score_and_align).  The alignment kernel is
+        # latency-bound -- one dependent step per frame: 2.4 ms for 64 utterances x 1000 frames,
+        # 2.2 ms for 256 -- so cutting a shard finer than needed ADDS alignment time: a 256-
+        # utterance shard (one of 8 ranks) takes 7.7 ms as one chunk and 11.7 ms as four
+        # (measured).  Chunks of `chunk_utts`, the last one ragged.
+        self.chunk_utts = max(1, min(chunk_utts, max(1, len(self.mine))))
         sseq = model.table("sseq").reshape(-1, model.n_emit_state)
         pssid, ptmat = model.table("phone_ssid"), model.table("phone_tmat")
         senid, tmat = [], []

@@ -93,30 +93,24 @@ def test_c_gather_entry_point_one_rank(gpu_en):
 
 def test_chunk_size_does_not_change_the_alignments(gpu_en, means_en):
     """a rank's shard is scored and aligned in chunks, scoring a chunk ahead of
-    alignment on a stream of its own into two ping-pong score buffers.  At 8 ranks the shard of
-    256 utterances is cut into four chunks of 64 where rounds 1-2 ran one chunk of 256; the
-    alignments must not depend on the cut.  A 256-utterance shard (what one of 8 ranks holds)
-    through chunks of 32, 64, 100 (ragged last chunk) and 256."""
+    alignment on a stream of its own into two ping-pong score buffers; the alignments must not
+    depend on the cut.  A 256-utterance shard (what one of 8 ranks holds) through chunks of 32,
+    64, 100 (ragged last chunk) and 256.  (How many chunks are FAST is a measurement: the
+    alignment kernel's time does not shrink with the chunk, so the default stays 256 --
+    DESIGN.md section 6.)"""
     from soundswallower_amd import jobs
-    crcs, chunk_seen = {}, {}
+    crcs, walls = {}, {}
     for chunk in (32, 64, 100, 256):
         shard = jobs.Config5Shard(gpu_en, means_en, rank=0, world=1, n_utts=256, n_frames=1000,
                                   n_phones=150, chunk_utts=chunk)
         try:
+            assert shard.chunk_utts == chunk
+            shard.run()
             r = shard.run()
         finally:
             shard.close()
         assert r["aligned"] == 256 and r["tiles"]
         crcs[chunk] = jobs.alignment_crc(r["per_utt"])
-        chunk_seen[chunk] = shard.chunk_utts
-    assert chunk_seen == {32: 32, 64: 64, 100: 64, 256: 64}   # never fewer than 4 chunks per rank
+        walls[chunk] = round(r["wall_s"] * 1e3, 2)
+    print("wall ms by chunk size:", walls)
     assert len(set(crcs.values())) == 1, crcs
-
-
-def test_default_chunking_leaves_every_rank_four_chunks(gpu_en, means_en):
-    from soundswallower_amd import jobs
-    for world, want in ((1, 256), (2, 256), (4, 128), (8, 64)):
-        s = jobs.Config5Shard.__new__(jobs.Config5Shard)
-        mine = jobs.shard_utterances([1000] * 2048, world)[0]
-        quarter = -(-len(mine) // 4)
-        assert max(1, min(jobs.CHUNK_UTTS, max(32, quarter), len(mine))) == want
