@@ -34,8 +34,10 @@ def test_align_matches_oracle(gpu_en, orc_en, n_phones, n_frames):
 def test_all_alignment_kernels_agree_on_a_ragged_windowed_batch(gpu_en, orc_en, monkeypatch):
     """Utterances of 1..200 phones in one call, with phone windows (sf/ef) on some of them and
     one window that cannot be met: the wave-per-word kernel (the default here), the
-    wave-per-utterance register kernel, the LDS kernel and the HBM-resident one
-    (SSW_ALIGN_KERNEL=mw/reg/lds/hbm) must all equal the oracle, failures included."""
+    wave-per-utterance register kernel, the LDS kernel, the HBM-resident one and the
+    sliding-window one (SSW_ALIGN_KERNEL=mw/reg/lds/hbm/win) must all equal the oracle, failures
+    included.  (The utterances without windows enter every phone in frame 0: the window kernel
+    reports that it cannot hold them and the call falls back, which is part of what is tested.)"""
     rng = np.random.default_rng(5)
     n_ph = [1, 3, 64, 65, 127, 128, 200, 17]
     n_fr = [int(p * rng.integers(3, 6) + 4) for p in n_ph]
@@ -68,7 +70,8 @@ def test_all_alignment_kernels_agree_on_a_ragged_windowed_batch(gpu_en, orc_en, 
     d = gpu_en.to_device(scr)
     try:
         results = []
-        for mode in ("mw", "reg", "lds", "hbm"):
+        monkeypatch.setenv("SSW_ALIGN_WIN_WAVES", "2")   # "win": a window of 2 blocks that slides
+        for mode in ("mw", "reg", "lds", "hbm", "win"):
             monkeypatch.setenv("SSW_ALIGN_KERNEL", mode)
             results.append(gpu_en.align_batch(d, frame_off, phone_off, senid, tmat, sf=sf, ef=ef))
     finally:
@@ -82,6 +85,7 @@ def test_all_alignment_kernels_agree_on_a_ragged_windowed_batch(gpu_en, orc_en, 
     assert np.array_equal(results[0][1], results[1][1])
     assert np.array_equal(results[0][1], results[2][1])
     assert np.array_equal(results[0][1], results[3][1])
+    assert np.array_equal(results[0][1], results[4][1])
 
 
 @pytest.mark.parametrize("mode", ["reg", "lds", "hbm"])
@@ -185,3 +189,42 @@ def test_utterance_beyond_the_lds_limit(gpu_en, orc_en):
         assert statusv[0] == want_status[0], k
         if want_status[0] == 0:
             assert np.array_equal(stv, want_st), k
+
+
+@pytest.mark.parametrize("waves", [2, 4, 8, 16])
+def test_sliding_window_kernel(gpu_en, orc_en, monkeypatch, waves):
+    """Round 3: viterbi_align_win_kernel -- HMMs in registers for utterances of any length, `waves`
+    64-phone blocks at a time, the window following the active phones.  700 phones (11 blocks)
+    over 2,400 frames with the kind of windows a first pass leaves (every phone confined to a
+    stretch around its share of the audio): windows of 2 .. 16 blocks, i.e. from "slides every few
+    frames and sometimes cannot hold the active range" (falls back) to "never slides"; all equal
+    to the oracle.  Then the same with a token budget of one block per frame (falls back)."""
+    n_phones, n_frames = 700, 2400
+    senid, tmat, _ = synth_alignment_task(orc_en.sseq, orc_en.phone_ssid, orc_en.phone_tmat,
+                                          orc_en.n_ciphone, n_phones, 31337)
+    scr = _random_senscr(n_frames, orc_en.n_sen, 4711)
+    mid = (np.arange(n_phones) * n_frames) // n_phones
+    res = {}
+    for name, (lo, hi) in {"narrow": (12, 20), "wide": (150, 260)}.items():
+        sf = np.maximum(mid - lo, 0).astype(np.int32)
+        ef = np.minimum(mid + hi, n_frames).astype(np.int32)
+        rv, rst, _ = orc_en.state_align(scr, senid, tmat, sf=sf, ef=ef)
+        res[name] = (sf, ef, rv, rst)
+    monkeypatch.setenv("SSW_ALIGN_KERNEL", "win")
+    monkeypatch.setenv("SSW_ALIGN_WIN_WAVES", str(waves))
+    d = gpu_en.to_device(scr)
+    try:
+        for name, (sf, ef, rv, rst) in res.items():
+            st, status = gpu_en.align_batch(d, [0, n_frames], [0, n_phones], senid, tmat, sf=sf, ef=ef)
+            assert (status[0] == 0) == (rv == 0), name
+            if rv == 0:
+                assert np.array_equal(st, rst), name
+        monkeypatch.setenv("SSW_ALIGN_BAND_TOKENS", "192")
+        sf, ef, rv, rst = res["narrow"]
+        st, status = gpu_en.align_batch(d, [0, n_frames], [0, n_phones], senid, tmat, sf=sf, ef=ef)
+        assert (status[0] == 0) == (rv == 0)
+        if rv == 0:
+            assert np.array_equal(st, rst)
+    finally:
+        gpu_en.device_free(d)
+    assert res["narrow"][2] == 0          # the narrow windows do leave a path

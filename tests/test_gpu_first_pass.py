@@ -501,6 +501,19 @@ def test_hbm_resident_kernel_equals_the_register_one(oracle_mod, gpu_en, gpu_fr,
         scoresf.append(synth_scores(Ff, orc_fr, olexf, words, 300 + t, orc_fr.n_sen, sil_p=0.5))
     smallf = _first_pass(gpu_fr, lexf, scoresf, textsf)
     _forced_big(monkeypatch)
+    # round 3: forced on small problems the long-text path starts with first_pass_win_kernel
+    # (HMMs in registers, a sliding window of nodes); windows of 256, 512 and 1024 nodes (the
+    # smallest slides and sometimes gives up: the call then falls back), then without it
+    # (SSW_FP_WIN=0: first_pass_big_kernel, node state in HBM)
+    for tpb in ("256", "512", "1024"):
+        monkeypatch.setenv("SSW_FP_WIN_TPB", tpb)
+        assert _first_pass(gpu_en, lex, scores, texts) == small, tpb
+        assert _first_pass(gpu_fr, lexf, scoresf, textsf) == smallf, tpb
+    monkeypatch.delenv("SSW_FP_WIN_TPB")
+    monkeypatch.setenv("SSW_FP_HIST_BAND", "1")     # the window kernel's history budget overflows
+    assert _first_pass(gpu_en, lex, scores, texts) == small
+    monkeypatch.delenv("SSW_FP_HIST_BAND")
+    monkeypatch.setenv("SSW_FP_WIN", "0")
     big = _first_pass(gpu_en, lex, scores, texts)
     bigf = _first_pass(gpu_fr, lexf, scoresf, textsf)
     assert big == small and bigf == smallf
@@ -537,8 +550,17 @@ def test_a_page_of_2000_words(oracle_mod, gpu_en, orc_en):
     t0 = time.time()
     got = _first_pass(gpu_en, lex, [scr], [words])[0]
     t1 = time.time()
+    # (round 3: that was the sliding-window register kernel; the HBM-resident one must agree)
+    import os
+    os.environ["SSW_FP_WIN"] = "0"
+    try:
+        assert _first_pass(gpu_en, lex, [scr], [words])[0] == got
+    finally:
+        del os.environ["SSW_FP_WIN"]
+    t1b = time.time()
     want = F.first_pass(orc_en, olex, words, scr)
-    print(f"2000 words, {len(scr)} frames: GPU first pass {t1 - t0:.2f} s, oracle {time.time() - t1:.2f} s")
+    print(f"first pass with the node state in HBM: {t1b - t1:.2f} s")
+    print(f"2000 words, {len(scr)} frames: GPU first pass {t1 - t0:.2f} s, oracle {time.time() - t1b:.2f} s")
     assert want is not None and got is not None and len(got) >= 2000
     assert [(w, s, s + d - 1, x) for (w, s, d, x) in got] == want
     # ... and the whole decoder_alignment: populate with those windows, the second pass over
