@@ -18,16 +18,20 @@ from soundswallower_amd.synth import read_raw_means, synth_features  # noqa: E40
 
 
 def soak_align(a):
-    """Random forced-alignment problems (ragged batches, random windows, all three kernels)."""
+    """Random forced-alignment problems (ragged batches, random windows, all five kernels in
+    rotation; the sliding-window one with windows of 2, 4 and 8 blocks, i.e. with and without
+    falling back)."""
     from soundswallower_amd.synth import lcg_uniform, synth_alignment_task
     mdir = ssw.model_dir(a.model)
     g, o = ssw.Model(mdir), O.Model(mdir)
     rng = np.random.default_rng(77)
     t0 = time.time()
-    n_utts = n_fail = bad = n_frames = 0
+    n_utts = n_fail = bad = n_frames = n_batches = 0
     while time.time() - t0 < a.seconds:
-        mode = ["mw", "reg", "lds", "hbm"][n_utts % 4]
+        mode = ["mw", "reg", "lds", "hbm", "win"][n_batches % 5]
         os.environ["SSW_ALIGN_KERNEL"] = mode
+        os.environ["SSW_ALIGN_WIN_WAVES"] = ["2", "4", "8"][(n_batches // 5) % 3]
+        n_batches += 1
         k = int(rng.integers(1, 7))
         n_ph = rng.integers(1, 300, size=k).tolist()
         n_fr = [int(p * rng.integers(2, 6) + rng.integers(0, 9)) for p in n_ph]
@@ -92,6 +96,16 @@ def soak_first_pass(a):
     t_end = time.time() + a.seconds
     n_utts = n_frames = n_fail = n_batches = n_label = 0
     while time.time() < t_end:
+        # round 3: every third batch through the long-text path (the sliding-window register
+        # kernel with windows of 256 / 512 nodes, falling back to the HBM-resident one when the
+        # window cannot hold the active nodes), every sixth through the HBM-resident one alone
+        for k_ in ("SSW_FP_KERNEL", "SSW_FP_WIN", "SSW_FP_WIN_TPB"):
+            os.environ.pop(k_, None)
+        if n_batches % 3 == 2:
+            os.environ["SSW_FP_KERNEL"] = "big"
+            os.environ["SSW_FP_WIN_TPB"] = ["256", "512"][(n_batches // 3) % 2]
+            if n_batches % 6 == 5:
+                os.environ["SSW_FP_WIN"] = "0"
         nb = int(rng.integers(1, 40))
         texts, scores = [], []
         for _ in range(nb):
@@ -171,6 +185,15 @@ def soak_text(a):
     t_end = time.time() + a.seconds
     n_utts = n_frames = n_fail = n_batches = 0
     while time.time() < t_end:
+        # round 3: every other batch through the long-text kernels of both passes (sliding
+        # windows of 256 nodes / 2 or 4 phone blocks, falling back where those cannot hold it)
+        for k_ in ("SSW_FP_KERNEL", "SSW_FP_WIN_TPB", "SSW_ALIGN_KERNEL", "SSW_ALIGN_WIN_WAVES"):
+            os.environ.pop(k_, None)
+        if n_batches % 2 == 1:
+            os.environ["SSW_FP_KERNEL"] = "big"
+            os.environ["SSW_FP_WIN_TPB"] = "256"
+            os.environ["SSW_ALIGN_KERNEL"] = "win"
+            os.environ["SSW_ALIGN_WIN_WAVES"] = ["2", "4"][(n_batches // 2) % 2]
         nb = int(rng.integers(1, 24))
         texts, scores = [], []
         for _ in range(nb):

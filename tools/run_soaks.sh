@@ -1,0 +1,17 @@
+#!/bin/bash
+# Randomised GPU-vs-oracle soaks on the current build (ON the GPU box):
+#   gpurun --timeout 3000 -- 'bash tools/run_soaks.sh r03 240'
+# Writes gpurun_out/<tag>_parity_soak_*.json (copy into profiles/ to keep them).
+tag=${1:-r03}
+secs=${2:-240}
+O=$GRAFT_REPO_ROOT/gpurun_out
+cd $GRAFT_REPO_ROOT
+python tests/soak_parity.py --mode ptm --seconds $secs > $O/${tag}_parity_soak_ptm.json 2> $O/${tag}_soak_ptm.err
+python tests/soak_parity.py --mode ptm --model fr-fr --seconds $((secs / 2)) > $O/${tag}_parity_soak_ptm_frfr.json 2> $O/${tag}_soak_ptm_frfr.err
+python tests/soak_parity.py --mode ms --model fr-fr --seconds $secs > $O/${tag}_parity_soak_ms.json 2> $O/${tag}_soak_ms.err
+python tests/soak_parity.py --mode align --seconds $secs > $O/${tag}_parity_soak_align.json 2> $O/${tag}_soak_align.err
+python tests/soak_parity.py --mode first_pass --seconds $secs > $O/${tag}_parity_soak_first_pass.json 2> $O/${tag}_soak_first_pass.err
+python tests/soak_parity.py --mode first_pass --model fr-fr --seconds $secs > $O/${tag}_parity_soak_first_pass_frfr.json 2> $O/${tag}_soak_first_pass_frfr.err
+python tests/soak_parity.py --mode text --seconds $secs > $O/${tag}_parity_soak_text.json 2> $O/${tag}_soak_text.err
+tail -n 2 $O/${tag}_parity_soak_*.json
+tail -n 3 $O/${tag}_soak_*.err
