@@ -228,3 +228,51 @@ def test_sliding_window_kernel(gpu_en, orc_en, monkeypatch, waves):
     finally:
         gpu_en.device_free(d)
     assert res["narrow"][2] == 0          # the narrow windows do leave a path
+
+
+@pytest.mark.parametrize("mode", ["mw", "win"])
+def test_edge_shapes_of_the_register_kernels(gpu_en, orc_en, monkeypatch, mode):
+    """Phone counts at the 64-phone block boundaries, utterances of 0, 1 and 2 frames, utterances
+    of very different lengths in one call -- through the wave-per-word kernel and through the
+    sliding-window one (window of 2 blocks: it slides, and gives up on the long unwindowed
+    ones); status and entries equal to the oracle for every utterance."""
+    monkeypatch.setenv("SSW_ALIGN_KERNEL", mode)
+    monkeypatch.setenv("SSW_ALIGN_WIN_WAVES", "2")
+    shapes = [(1, 0), (1, 1), (2, 1), (1, 2), (3, 2), (63, 200), (64, 200), (65, 210), (127, 400),
+              (128, 400), (129, 420), (192, 600), (5, 3), (300, 950)]
+    n_ph = [a for a, _ in shapes]
+    n_fr = [b for _, b in shapes]
+    frame_off = np.concatenate([[0], np.cumsum(n_fr)]).astype(np.int32)
+    phone_off = np.concatenate([[0], np.cumsum(n_ph)]).astype(np.int32)
+    scr = _random_senscr(int(frame_off[-1]), orc_en.n_sen, 2718)
+    senid, tmat, sf, ef = [], [], [], []
+    for u, (p, f) in enumerate(shapes):
+        s_, t_, _ = synth_alignment_task(orc_en.sseq, orc_en.phone_ssid, orc_en.phone_tmat,
+                                         orc_en.n_ciphone, p, 900 + u)
+        senid.append(s_)
+        tmat.append(t_)
+        a = np.zeros(p, np.int32)
+        b = np.full(p, 2**31 - 1, np.int32)
+        if p >= 63 and u % 2 == 1:      # windows on every other long one
+            mid = (np.arange(p) * f) // p
+            a = np.maximum(mid - 5, 0).astype(np.int32)
+            b = np.minimum(mid + f // p + 7, f).astype(np.int32)
+        sf.append(a)
+        ef.append(b)
+    senid, tmat = np.concatenate(senid), np.concatenate(tmat)
+    sf, ef = np.concatenate(sf), np.concatenate(ef)
+    d = gpu_en.to_device(scr) if len(scr) else None
+    try:
+        st, status = gpu_en.align_batch(d, frame_off, phone_off, senid, tmat, sf=sf, ef=ef)
+    finally:
+        gpu_en.device_free(d)
+    n_ok = 0
+    for u in range(len(shapes)):
+        sl = slice(phone_off[u], phone_off[u + 1])
+        rv, rst, _ = orc_en.state_align(scr[frame_off[u]:frame_off[u + 1]], senid[sl], tmat[sl],
+                                        sf=sf[sl], ef=ef[sl])
+        assert (status[u] == 0) == (rv == 0), (u, shapes[u], status[u], rv)
+        if rv == 0:
+            n_ok += 1
+            assert np.array_equal(st[phone_off[u] * 3:phone_off[u + 1] * 3], rst), (u, shapes[u])
+    assert n_ok >= 8

@@ -337,15 +337,26 @@ def test_edge_shapes(oracle_mod, gpu_en, orc_en):
     one = synth_scores(F, orc_en, olex, ["go"], 2, orc_en.n_sen)
     texts = [[], ["go"], ["go"], ["go", "forward"], ["go"], []]
     scores = [sil, one, np.zeros((0, orc_en.n_sen), np.int16), one[:1], one[:3], one]
-    got = _first_pass(gpu_en, lex, scores, texts)
-    for t, sc, g in zip(texts, scores, got):
-        want = F.first_pass(orc_en, olex, t, sc) if len(sc) else None
-        if want is None:
-            assert g is None, (t, len(sc))
-        else:
-            assert g is not None and [(w, s, s + d - 1, x) for (w, s, d, x) in g] == want, (t, len(sc))
-    assert got[0] is not None and all(w == "<sil>" for (w, _, _, _) in got[0])
-    assert got[1] is not None and got[2] is None
+    import os
+    # the register kernel, then (round 3) the long-text kernels forced on these shapes: the
+    # sliding-window one and the HBM-resident one
+    for env in ({}, {"SSW_FP_KERNEL": "big", "SSW_FP_WIN_TPB": "256"},
+                {"SSW_FP_KERNEL": "big", "SSW_FP_WIN": "0"}):
+        os.environ.update(env)
+        try:
+            got = _first_pass(gpu_en, lex, scores, texts)
+        finally:
+            for k in env:
+                del os.environ[k]
+        for t, sc, g in zip(texts, scores, got):
+            want = F.first_pass(orc_en, olex, t, sc) if len(sc) else None
+            if want is None:
+                assert g is None, (t, len(sc), env)
+            else:
+                assert g is not None and [(w, s, s + d - 1, x) for (w, s, d, x) in g] == want, \
+                    (t, len(sc), env)
+        assert got[0] is not None and all(w == "<sil>" for (w, _, _, _) in got[0])
+        assert got[1] is not None and got[2] is None
 
 
 def test_full_size_properties(gpu_en):
