@@ -264,6 +264,22 @@ def test_ptm_runs_of_history_dependent_frames_across_tiles(gpu_en, orc_en, means
     assert flagged >= 300, "the runs should put many pairs through the exact pass"
     assert np.array_equal(gcw.astype(np.int32), rcw)
     assert np.array_equal(got, ref)
+    if total >= 2600:
+        # round 3: large batches are scored in pieces (scan + senone per ~16 K frames); pieces of
+        # 512 and 768 frames here, so that their edges fall inside the runs: a piece's first
+        # frame re-derives the order it starts from by walking back into the piece before
+        import os
+        for piece in ("512", "768"):
+            os.environ["SSW_SCORE_PIECE"] = piece
+            try:
+                got2 = gpu_en.score_batch(feats, off)
+                f2, p2 = gpu_en.last_stats()
+                gcw2, _ = gpu_en.last_topn(len(feats))
+            finally:
+                del os.environ["SSW_SCORE_PIECE"]
+            assert p2 == pairs and f2 == flagged, piece
+            assert np.array_equal(gcw2.astype(np.int32), rcw), piece
+            assert np.array_equal(got2, ref), piece
 
 
 def _tie_heavy_features(orc, means, total, seed):
