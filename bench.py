@@ -92,6 +92,10 @@ def align_config3(ssw, model, means, torch, n_utts=256, n_frames=1000, n_phones=
     d_scr = torch.empty((total, model.n_sen), dtype=torch.int16, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     best = None
+    t_spin = time.perf_counter()     # the GPU idled while the host made the inputs (see spin_up)
+    while time.perf_counter() - t_spin < 0.3:
+        model.score_batch_device(d_feats, total, frame_off, d_scr, stream)
+        torch.cuda.synchronize()
     for _ in range(reps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -432,6 +436,7 @@ def main():
         bf = np.concatenate([ssw.synth_features(means, UTT_FRAMES, 12345 + u) for u in range(big_utts)])
         boff = (np.arange(big_utts + 1) * UTT_FRAMES).astype(np.int32)
         big = ScoreStep(torch, model, bf, boff)
+        spin_up(torch, big, 0.3)   # the GPU idled while the host made the features (as for `value`)
         e = timed_steps(torch, None, backend, big, 3, 20)
         bk = big.kernel_ms(10)
         bab = algorithmic_bytes(model.n_sen, model.n_feat, model.topn, model.n_cb,
@@ -483,6 +488,7 @@ def real_features(ssw, model, torch, steps=50):
     tiled = np.tile(feat, (reps, 1))[:N_UTTS * UTT_FRAMES].copy()
     off = (np.arange(N_UTTS + 1) * UTT_FRAMES).astype(np.int32)
     st = ScoreStep(torch, model, tiled, off)
+    spin_up(torch, st, 0.3)
     e = timed_steps(torch, None, "nccl", st, 5, steps)
     k = st.kernel_ms(10)
     flagged, pairs = model.last_stats()

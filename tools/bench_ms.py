@@ -64,6 +64,11 @@ def run(utts=32, frames=256, steps=100, warmup=10):
     def step():
         m.score_batch_device(d_feats, n, off, d_out, scorer=ssw.SCORER_MS)
 
+    t_spin = time.perf_counter()      # ~0.3 s of the step itself: the GPU idled while the host
+    while time.perf_counter() - t_spin < 0.3:   # made the model and the features (bench.py spin_up)
+        for _ in range(50):
+            step()
+        L.ssw_device_synchronize()
     for _ in range(warmup):
         step()
     L.ssw_device_synchronize()
