@@ -315,7 +315,7 @@ def main():
 
     step = ScoreStep(torch, model, feats, utt_off)
     if not os.environ.get("SSW_BENCH_NO_SPIN"):   # (tools/pmc_pass.py: keep the trace short)
-        spin_up(torch, step)
+        spin_up(torch, step, float(os.environ.get("SSW_BENCH_SPIN", "0.5")))
     elapsed = timed_steps(torch, dist, backend, step, args.warmup, args.steps)
     k_ms = step.kernel_ms(max(1, min(args.steps, 50)))
     flagged, pairs = model.last_stats()
