@@ -1,6 +1,7 @@
 """The sharded batch-alignment job of BASELINE.json configs[4] ("config 5" in SURVEY.md 8(d)):
 N synthetic utterances x F frames x P phones, dealt over the ranks of one node; every rank
-scores its utterances (ssw_score_batch) and force-aligns them (ssw_align_batch) in chunks, and
+scores its utterances (ssw_score_batch) and force-aligns them (ssw_align_batch) -- the whole shard
+at once while its scores fit in HBM, in chunks beyond that -- and
 the final state alignments are gathered once (parallel.gather_alignments: RCCL on a GPU node,
 gloo in the CPU tests).  Used by bench.py (`config5` object of the bench line),
 tools/bench_align.py and tests/test_gpu_config5.py, so all three run the same code.
@@ -20,6 +21,7 @@ from .parallel import gather_alignments, shard_utterances
 from .synth import synth_alignment_task, synth_features
 
 N_UTTS, N_FRAMES, N_PHONES, CHUNK_UTTS = 2048, 1000, 150, 256
+RESIDENT_BYTES = 64 << 30   # a shard whose senone scores take less stays resident as a whole
 
 
 class Config5Shard:
@@ -57,9 +59,17 @@ class Config5Shard:
                 f = synth_features(means, n_frames, 12345 + u)
                 model._L.ssw_memcpy_h2d(self.d_feats + k * n_frames * row,
                                         f.ctypes.data, f.nbytes)
+            # Round 3: when the shard's scores fit in HBM (21 GB for 2048 x 1000 frames; the GPU
+            # has 288) the whole shard is scored, then aligned in ONE call: the alignment kernel
+            # is latency-bound -- 1.3 ms per 1000 frames for 256 utterances, and barely more for
+            # 2048 (six waves per SIMD instead of one) -- so eight calls beside the scoring of the
+            # next chunk (each three times slower for sharing the chip, and slowing the scoring)
+            # cost more than one call at the end.  Beyond RESIDENT_BYTES: chunks, ping-pong.
+            total = len(self.mine) * n_frames * model.n_sen * 2
+            self.resident = total <= RESIDENT_BYTES and chunk_utts >= CHUNK_UTTS
             nbytes = self.chunk_utts * n_frames * model.n_sen * 2
-            self.d_scr = model.device_malloc(2 * nbytes)      # two score buffers, ping-pong
-            self.d_scr2 = (self.d_scr, self.d_scr + nbytes)
+            self.d_scr = model.device_malloc(total if self.resident else 2 * nbytes)
+            self.d_scr2 = (self.d_scr, self.d_scr + (0 if self.resident else nbytes))
             self.s_score = model._L.ssw_stream_create()
             self.s_align = model._L.ssw_stream_create()
 
@@ -89,6 +99,17 @@ class Config5Shard:
         chunks = [(c0, min(n_mine, c0 + self.chunk_utts)) for c0 in range(0, n_mine, self.chunk_utts)]
         if not chunks:
             return states, status, 0.0, 0.0
+        if self.resident:
+            frame_off = (np.arange(n_mine + 1) * F).astype(np.int32)
+            phone_off = (np.arange(n_mine + 1) * P).astype(np.int32)
+            ta = time.perf_counter()
+            m.score_batch_device(self.d_feats, n_mine * F, frame_off, self.d_scr, self.s_score)
+            L.ssw_stream_synchronize(self.s_score)
+            tb = time.perf_counter()
+            st, stat = m.align_batch(self.d_scr, frame_off, phone_off, self.senid, self.tmat,
+                                     stream=self.s_align)
+            tc = time.perf_counter()
+            return st, stat, tb - ta, tc - tb
 
         def launch_score(k):
             c0, c1 = chunks[k]
