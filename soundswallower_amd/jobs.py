@@ -50,6 +50,7 @@ class Config5Shard:
                       else np.zeros((0, model.n_emit_state), np.uint16))
         self.tmat = np.concatenate(tmat) if tmat else np.zeros(0, np.int16)
         self.d_feats, self.d_scr = None, None
+        self.resident = False
         self.s_score = self.s_align = None
         if self.mine:
             # uploaded chunk by chunk: the host never holds more than one chunk of features
@@ -208,9 +209,12 @@ def run_config5(model, means, dist=None, rank=0, world=1, device=None, reps=2, n
     complete = all(a is not None for a in per_utt)
     return {
         "workload": f"{n_utts} utterances x {n_frames} frames x {n_phones} phones, en-us, dealt "
-                    f"over {world} rank(s) in chunks of {shard.chunk_utts} utterances: PTM "
-                    f"scoring + forced alignment per rank, one gather of the state alignments "
-                    f"(BASELINE configs[4])",
+                    f"over {world} rank(s), "
+                    + ("every shard scored as a whole and aligned in one call"
+                       if getattr(shard, "resident", False)
+                       else f"in chunks of {shard.chunk_utts} utterances")
+                    + ": PTM scoring + forced alignment per rank, one gather of the state "
+                      "alignments (BASELINE configs[4])",
         "n_ranks": world, "n_utts": n_utts,
         "wall_ms": best["wall_s"] * 1e3, "score_ms": best["score_s"] * 1e3,
         "align_ms": best["align_s"] * 1e3, "gather_ms": best["gather_s"] * 1e3,
