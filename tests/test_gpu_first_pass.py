@@ -633,3 +633,32 @@ def test_long_and_short_texts_in_one_batch(oracle_mod, gpu_en, orc_en):
         assert [w for (w, _, _, _) in want] == a["words"]
     assert len(both.utterance(1)["cipid"]) > 2560
     both.free()
+
+
+@pytest.mark.timeout(600)
+def test_sliding_window_with_twins(oracle_mod, gpu_fr, orc_fr, monkeypatch):
+    """The window kernel's rings under the twins' bookkeeping: fr-fr texts of 130 words full of
+    alternates that are pronounced alike (their word-final HMMs follow the reference's list order
+    through per-group records of node ids and the nodes' flags, which live in a ring here), long
+    enough that a window of 256 nodes slides dozens of times.  Equal to the register kernel
+    (two nodes per thread) and, for one of them, to the oracle."""
+    F, olex = _olex(oracle_mod, orc_fr, "fr-fr")
+    lex = _lex(gpu_fr, "fr-fr")
+    pool = ["abus", "ait", "mauritaniens", "avance", "de", "dix", "mètres"]
+    pool = [w for w in pool if w in olex.pron]
+    assert len(pool) >= 4
+    u = lcg_uniform(4242, 3 * 130)
+    texts = [[pool[int(x * len(pool))] for x in u[t * 130:(t + 1) * 130]] for t in range(3)]
+    scores = [synth_scores(F, orc_fr, olex, t, 800 + i, orc_fr.n_sen, sil_p=0.3,
+                           noise_lo=60 if i else 120)
+              for i, t in enumerate(texts)]
+    n_nodes = [len(lex.first_pass_graph(t, max_nodes=1 << 16)[0]) for t in texts]
+    assert min(n_nodes) > 1024 and max(n_nodes) <= 2048, n_nodes
+    small = _first_pass(gpu_fr, lex, scores, texts)       # first_pass_kernel<2, 1024>
+    assert all(g is not None for g in small)
+    monkeypatch.setenv("SSW_FP_KERNEL", "big")
+    for tpb in ("256", "512"):
+        monkeypatch.setenv("SSW_FP_WIN_TPB", tpb)
+        assert _first_pass(gpu_fr, lex, scores, texts) == small, tpb
+    want = F.first_pass(orc_fr, olex, texts[0], scores[0])
+    assert [(w, s, s + d - 1, x) for (w, s, d, x) in small[0]] == want
