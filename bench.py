@@ -18,7 +18,7 @@ Prints ONE JSON line on rank 0, including
                  dealt over the N ranks, each rank scoring and force-aligning its shard, ONE
                  gather of the final alignments over RCCL; job utterance-frames/s, align RTF,
                  gather_ms and a CRC of the gathered alignments that does not depend on N;
-  `batch_65536`, `real_features`, `align`, `text_align`  (N = 1 only) the same scoring step
+  `batch_16384`, `batch_65536`, `real_features`, `align`, `text_align`  (N = 1 only) the same scoring step
                  at 65,536 frames, on features of a real recording, and BASELINE configs[2]
                  from phone strings and from text;
   `config4`      (N = 1 only) BASELINE configs[3]: the ms scorer on fr-fr, 8192 frames per step.
@@ -431,22 +431,27 @@ def main():
     if c5 is not None:
         out["config5"] = c5
     if world == 1 and args.model == "en-us" and not args.no_extra:
-        # north_star says "batch >= 4096 frames": the same step at 65,536 frames per launch
-        big_utts = 256
-        bf = np.concatenate([ssw.synth_features(means, UTT_FRAMES, 12345 + u) for u in range(big_utts)])
-        boff = (np.arange(big_utts + 1) * UTT_FRAMES).astype(np.int32)
-        big = ScoreStep(torch, model, bf, boff)
-        spin_up(torch, big, 0.3)   # the GPU idled while the host made the features (as for `value`)
-        e = timed_steps(torch, None, backend, big, 3, 20)
-        bk = big.kernel_ms(10)
-        bab = algorithmic_bytes(model.n_sen, model.n_feat, model.topn, model.n_cb,
-                                model.n_density, model.veclen_total, big.n_frames)
-        out["batch_65536"] = {
-            "workload": f"the same step at {big.n_frames} frames per launch ({big_utts} x 256)",
-            "frames_per_s": big.n_frames * 20 / e, "ms_per_step": e / 20 * 1e3,
-            "kernel_ms": float(bk.sum()),
-            "roofline_frac": bab["path"] * big.n_frames / (float(bk.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        del big
+        # north_star says "batch >= 4096 frames": the same step at 16,384 frames per launch (the
+        # size at which a frame costs least: DESIGN.md section 5) and at 65,536 (scored in four
+        # pieces of 16,384).  roofline_frac: from the wall time of the steps, like the headline's
+        # `frac` as the driver recomputes it; roofline_frac_kernels: from the kernels' own time
+        for big_utts in (64, 256):
+            bf = np.concatenate([ssw.synth_features(means, UTT_FRAMES, 12345 + u) for u in range(big_utts)])
+            boff = (np.arange(big_utts + 1) * UTT_FRAMES).astype(np.int32)
+            big = ScoreStep(torch, model, bf, boff)
+            spin_up(torch, big, 0.3)   # the GPU idled while the host made the features (as for `value`)
+            nst = 40 if big_utts == 64 else 20
+            e = timed_steps(torch, None, backend, big, 3, nst)
+            bk = big.kernel_ms(10)
+            bab = algorithmic_bytes(model.n_sen, model.n_feat, model.topn, model.n_cb,
+                                    model.n_density, model.veclen_total, big.n_frames)
+            out[f"batch_{big.n_frames}"] = {
+                "workload": f"the same step at {big.n_frames} frames per launch ({big_utts} x 256)",
+                "frames_per_s": big.n_frames * nst / e, "ms_per_step": e / nst * 1e3,
+                "kernel_ms": float(bk.sum()),
+                "roofline_frac": bab["path"] * big.n_frames * nst / e / 1e9 / HBM_PEAK_GBS,
+                "roofline_frac_kernels": bab["path"] * big.n_frames / (float(bk.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del big
         rf = real_features(ssw, model, torch)
         if rf is not None:
             out["real_features"] = rf
