@@ -96,4 +96,24 @@ def test_second_pass_scored_from_the_first_pass_history(gpu_en, orc_en, oracle_m
     finally:
         aset.free()
         plain.free()
+    # The same utterances 20 times over in one batch (5.6 K frames: the matrix-core scan), scored in
+    # pieces of 1024 frames: every utterance's second pass must start from ITS OWN first pass's
+    # last order (a row per utterance on the device), wherever the piece edges fall
+    import os
+    reps = 20
+    big = np.concatenate([real, coarse] * (reps // 2))
+    boff = (np.arange(reps + 1) * n).astype(np.int32)
+    os.environ["SSW_SCORE_PIECE"] = "1024"
+    try:
+        bset = ssw.align_text_batch(gpu_en, lex, torch.from_numpy(big).cuda(), boff, [TEXT] * reps,
+                                    cfg=cfg)
+    finally:
+        del os.environ["SSW_SCORE_PIECE"]
+    try:
+        for u in range(reps):
+            got = bset.utterance(u)
+            assert got is not None and got["words"] == want[u % 2][0], u
+            assert np.array_equal(got["state_al"], want[u % 2][1]), u
+    finally:
+        bset.free()
         lex.free()
