@@ -326,3 +326,17 @@ def test_history_carried_between_calls_and_utterances(gpu_en, orc_en, means_en):
     ref_reset = np.concatenate([orc_en.ptm_score_utt(feats[off[u]:off[u + 1]])
                                 for u in range(len(off) - 1) if off[u + 1] > off[u]])
     assert np.array_equal(plain, ref_reset)
+    # round 3: the same calls with the batch scored in pieces (large batches are; here pieces of
+    # 512 frames, whose edges fall inside the runs): carried chains, carry_in and resets alike
+    import os
+    os.environ["SSW_SCORE_PIECE"] = "512"
+    try:
+        carried2, _ = gpu_en.score_batch_carry(feats, off, carry_utts=True)
+        a2, carry = gpu_en.score_batch_carry(feats[:2400])
+        b2, _ = gpu_en.score_batch_carry(feats[2400:], carry_in=carry)
+        plain2 = gpu_en.score_batch(feats, off)
+    finally:
+        del os.environ["SSW_SCORE_PIECE"]
+    assert np.array_equal(carried2, ref_chain)
+    assert np.array_equal(np.concatenate([a2, b2]), ref_chain)
+    assert np.array_equal(plain2, ref_reset)
