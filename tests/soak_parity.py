@@ -194,10 +194,11 @@ def soak_text(a):
             os.environ["SSW_FP_WIN_TPB"] = "256"
             os.environ["SSW_ALIGN_KERNEL"] = "win"
             os.environ["SSW_ALIGN_WIN_WAVES"] = ["2", "4"][(n_batches // 2) % 2]
-        nb = int(rng.integers(1, 24))
+        nb = int(rng.integers(1, 24 if a.max_words < 50 else 4))
         texts, scores = [], []
         for _ in range(nb):
-            words = [vocab[int(rng.integers(len(vocab)))] for _ in range(int(rng.integers(1, 10)))]
+            words = [vocab[int(rng.integers(len(vocab)))]
+                     for _ in range(int(rng.integers(a.min_words, a.max_words + 1)))]
             sc = synth_scores(F, orc, olex, words, int(rng.integers(1 << 30)), orc.n_sen,
                               noise_lo=int(rng.choice([120, 60, 30])), sil_p=float(rng.random()))
             if rng.random() < 0.1:
@@ -244,6 +245,10 @@ def soak_text(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--min-words", type=int, default=1, help="text mode: words per text")
+    ap.add_argument("--max-words", type=int, default=9,
+                    help="text mode: words per text (hundreds: the sliding windows of the "
+                         "long-text kernels move, every other batch)")
     ap.add_argument("--model", default="en-us")
     ap.add_argument("--mode", default="ptm", choices=["ptm", "ms", "align", "first_pass", "text"])
     ap.add_argument("--max-len", type=int, default=400,
