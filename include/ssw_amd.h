@@ -126,11 +126,26 @@ int ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_
  * (acmod_start_utt only resets frame_idx, src/acmod.c:367) and across acmod_rewind from the
  * first pass of forced alignment into the second (src/decoder.c:786-793, src/ptm_mgau.c:425-448);
  * only the codeword ORDER matters (tie-breaks among equal truncated scores).
- *   flags      SSW_SCORE_CARRY_UTTS: no reset at the utterance boundaries of the batch
+ * The reference's history is a ring of TWO slots indexed by frame % 2 (n_fast_hist = 2,
+ * src/ptm_mgau.c:425-437, :804) and frame numbers restart at 0 with every utterance and after
+ * acmod_rewind: frame t > 0 starts from frame t - 1, but frame 0 copies slot 1 -- the final order
+ * of the last ODD-numbered frame scored before it.  After an utterance of even length that is
+ * its last frame; after one of odd length T >= 3 it is frame T - 2; an utterance of one frame
+ * leaves slot 1 as it found it.
+ *   flags      SSW_SCORE_CARRY_UTTS: no reset at the utterance boundaries of the batch: each
+ *              utterance's frame 0 starts from slot 1 as the utterances before it left it
+ *              SSW_SCORE_CARRY_OUT_REWIND: see carry_out
  *   carry_in   optional uint32 [n_cb * n_feat], 4 codewords packed best first: the order the
  *              batch's first frame starts from (NULL = the reset history)
- *   carry_out  optional uint32 [n_cb * n_feat]: the order after the batch's last frame (makes the
- *              call synchronous) -- pass it as carry_in of the next call / the second pass.
+ *   carry_out  optional uint32 [n_cb * n_feat] (makes the call synchronous).  Default: the order
+ *              after the batch's last frame -- carry_in of a call that CONTINUES the same utterance
+ *              (cut it after an even number of frames if an utterance boundary with
+ *              SSW_SCORE_CARRY_UTTS follows, so that the parity of its frames is kept).  With
+ *              SSW_SCORE_CARRY_OUT_REWIND: slot 1 after the batch -- carry_in of the next
+ *              UTTERANCE, or of the second pass of decoder_alignment over the same utterance after
+ *              acmod_rewind (with SSW_SCORE_CARRY_UTTS the batch's utterances are walked back to
+ *              the last one with two frames; without it only the last utterance counts; if no
+ *              frame wrote the slot, carry_in / the reset order comes back).
  * The ms scorer keeps no history: the three are ignored for it. */
 #define SSW_SCORE_CARRY_UTTS 1u
 /* the caller runs kernels of ANOTHER stream beside this call (the alignment of the previous
@@ -138,6 +153,7 @@ int ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_
  * persistent scoring workgroups then leave after 8 frame pairs instead of staying for the
  * whole batch, so the other stream finds free wave slots every ~100 us.  Same results. */
 #define SSW_SCORE_SHARE_DEVICE 2u
+#define SSW_SCORE_CARRY_OUT_REWIND 4u
 int ssw_score_batch_ex(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_frames,
                        const int32_t *utt_off, int32_t n_utts, int16_t *d_out, void *stream,
                        uint32_t flags, const uint32_t *carry_in, uint32_t *carry_out);

@@ -261,6 +261,23 @@ class Model:
         self._l.orc_ptm_score_utt(self._m, _ptr(feats), n, _ptr(out), None, None)
         return out
 
+    def ptm_score_chain(self, feats, utt_off, reset=True):
+        """Several utterances scored one after the other by ONE scorer, as a decoder does:
+        acmod_start_utt puts frame_idx back to 0 and never resets the top-N history
+        (src/acmod.c:367), so frame 0 of an utterance copies history slot 1 of the two-slot ring
+        (src/ptm_mgau.c:425-437) -- the last odd-numbered frame scored before it."""
+        feats = np.ascontiguousarray(feats, dtype=np.float32).reshape(-1, self.veclen_total)
+        if reset:
+            self.ptm_reset()
+        out = np.zeros((len(feats), self.n_sen), np.int16)
+        for u in range(len(utt_off) - 1):
+            self.ptm_set_frame_idx(0)
+            for t in range(int(utt_off[u]), int(utt_off[u + 1])):
+                i = t - int(utt_off[u])
+                out[t] = self.ptm_frame_eval(feats[t], i)
+                self.ptm_set_frame_idx(i + 1)
+        return out
+
     # ---- ms -----------------------------------------------------------------------
     def ms_score_utt(self, feats):
         feats = np.ascontiguousarray(feats, dtype=np.float32).reshape(-1, self.veclen_total)

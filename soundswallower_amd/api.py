@@ -151,9 +151,12 @@ class Model:
                "ssw_score_batch")
 
     def score_batch_carry(self, feats, utt_off=None, carry_in=None, carry_utts=False,
-                          scorer=SCORER_PTM):
+                          scorer=SCORER_PTM, rewind=False):
         """ssw_score_batch_ex on host features: returns (scores int16 [n][n_sen], carry_out
-        uint32 [n_cb * n_feat]); carry_in = the carry_out of an earlier call (or None)."""
+        uint32 [n_cb * n_feat]); carry_in = the carry_out of an earlier call (or None).
+        rewind = SSW_SCORE_CARRY_OUT_REWIND: carry_out is what the NEXT utterance, or the second
+        pass over this one after acmod_rewind, starts from (history slot 1 of the reference's
+        ring) instead of what a continuation of the same utterance starts from."""
         feats = np.ascontiguousarray(feats, dtype=np.float32).reshape(-1, self.veclen_total)
         n = feats.shape[0]
         off = (np.array([0, n], np.int32) if utt_off is None
@@ -163,11 +166,12 @@ class Model:
         cout = np.zeros(self.n_cb * self.n_feat, np.uint32)
         if n == 0:
             return out, (cin.copy() if cin is not None else np.full_like(cout, 0x03020100))
+        flags = (1 if carry_utts else 0) | (4 if rewind else 0)
         d_in = self.to_device(feats)
         d_out = self.device_malloc(out.nbytes)
         try:
             _check(self._L.ssw_score_batch_ex(self._m, scorer, d_in, n, _ptr(off), len(off) - 1,
-                                              d_out, None, 1 if carry_utts else 0, _ptr(cin),
+                                              d_out, None, flags, _ptr(cin),
                                               _ptr(cout)), "ssw_score_batch_ex")
             _check(self._L.ssw_memcpy_d2h(_ptr(out), d_out, out.nbytes), "ssw_memcpy_d2h")
         finally:

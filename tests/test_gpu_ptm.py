@@ -340,3 +340,109 @@ def test_history_carried_between_calls_and_utterances(gpu_en, orc_en, means_en):
     assert np.array_equal(carried2, ref_chain)
     assert np.array_equal(np.concatenate([a2, b2]), ref_chain)
     assert np.array_equal(plain2, ref_reset)
+
+
+def _ring_features(orc, means, total):
+    """Utterances whose boundaries show the reference's two-slot history ring: triplets (y, z, x)
+    of frames, found with the oracle, such that x scored after y differs from x scored after z.
+    `... y z | x ...` with y at an odd frame number and z the last frame of its utterance (odd
+    length): the next utterance's frame 0 copies slot 1 = y's order, not z's
+    (src/ptm_mgau.c:425-437).  Also `... y | z | x ...` (a one-frame utterance writes slot 0 only)
+    and an utterance without frames.  Filled up to `total` frames with the tie-heavy runs."""
+    cand = (np.round(synth_features(means, 600, 31337) * 8.0) / 8.0).astype(np.float32)
+    bad = _unprovable_pairs(orc, means, cand).reshape(len(cand), -1).sum(axis=1)
+    xs = np.argsort(-bad)[:8]
+    trip = []
+    for xi in xs:
+        rows = {}
+        for yi in range(0, 60):
+            r = orc.ptm_score_utt(np.stack([cand[yi], cand[xi]]))[1]
+            rows.setdefault(r.tobytes(), []).append(yi)
+        groups = sorted(rows.values(), key=len)
+        if len(groups) >= 2:
+            trip.append((groups[0][0], groups[-1][0], xi))      # (y, z, x): x differs after them
+    assert len(trip) >= 3, "no history-sensitive triplets among the candidates"
+    filler = synth_features(means, 64, 999)
+    parts, lens = [], []
+
+    def utt(*rows):
+        a = np.stack(rows) if rows else np.zeros((0, 39), np.float32)
+        parts.append(a.astype(np.float32))
+        lens.append(len(a))
+    k = 0
+    for (y, z, x) in trip:
+        f = [filler[(k + i) % 64] for i in range(5)]
+        utt(f[0], cand[y], cand[z])                 # odd: slot 1 = y
+        utt(cand[x], f[1], f[2], cand[y])           # even, ends on y (odd number)
+        utt(cand[z])                                # one frame: slot 1 still y
+        utt()                                       # no frame
+        utt(cand[z])                                # another one
+        utt(cand[x], f[3], cand[y], cand[z], f[4])  # odd (5): slot 1 = z at number 3
+        utt(cand[x], cand[y])
+        k += 5
+    rest = total - sum(lens)
+    tie = _tie_heavy_features(orc, means, rest, 11)
+    cut = [c for c in (0, 3, 334, 335, 351, 492) if c < rest] + [rest]
+    for a, b in zip(cut[:-1], cut[1:]):
+        parts.append(tie[a:b])
+        lens.append(b - a)
+    feats = np.ascontiguousarray(np.concatenate(parts), np.float32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    return feats, off
+
+
+def test_chain_over_utterances_follows_the_two_slot_ring(gpu_en, orc_en, means_en, monkeypatch):
+    """the reference's history is a ring of two slots indexed by frame % 2 and frame
+    numbers restart with every utterance (src/ptm_mgau.c:425-437, src/acmod.c:367), so frame 0
+    of an utterance starts from the last ODD-numbered frame before it: frame T - 2 of a
+    predecessor of odd length T, further back across one-frame utterances.  The boundaries are
+    built so that the choice shows (_ring_features); the oracle scores the utterances one after
+    the other with its own ring.  All three top-N kernels, and carry_in / carry_out with
+    SSW_SCORE_CARRY_OUT_REWIND across two calls."""
+    feats, off = _ring_features(orc_en, means_en, 4700)
+    want = orc_en.ptm_score_chain(feats, off)
+    one_utt = orc_en.ptm_score_utt(feats)
+    differ = np.nonzero((want != one_utt).any(axis=1))[0]
+    assert len(differ) >= 6, differ               # the ring matters on this input
+    got, _ = gpu_en.score_batch_carry(feats, off, carry_utts=True)            # matrix-core scan
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("SSW_SCAN", "fma")
+    got, _ = gpu_en.score_batch_carry(feats, off, carry_utts=True)            # vector-unit scan
+    monkeypatch.delenv("SSW_SCAN")
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("SSW_SCORE_PIECE", "512")
+    got, _ = gpu_en.score_batch_carry(feats, off, carry_utts=True)            # pieces
+    monkeypatch.delenv("SSW_SCORE_PIECE")
+    assert np.array_equal(got, want)
+    # two calls (small ones: vector-unit scan, one frame per lane): the first hands slot 1 over
+    # with SSW_SCORE_CARRY_OUT_REWIND, whatever the lengths of its last utterances
+    for cut_u in range(1, 16):
+        cut = int(off[cut_u])
+        a, carry = gpu_en.score_batch_carry(feats[:cut], off[:cut_u + 1], carry_utts=True,
+                                            rewind=True)
+        b, _ = gpu_en.score_batch_carry(feats[cut:], off[cut_u:] - cut, carry_in=carry,
+                                        carry_utts=True)
+        assert np.array_equal(np.concatenate([a, b]), want), cut_u
+    # a first call of one-frame utterances only hands its carry_in through
+    mark = np.full(126, 0x05040302, np.uint32)
+    _, carry = gpu_en.score_batch_carry(feats[:2], [0, 1, 2], carry_in=mark, carry_utts=True,
+                                        rewind=True)
+    assert np.array_equal(carry, mark)
+    _, carry = gpu_en.score_batch_carry(feats[:1], rewind=True)
+    assert (carry == 0x03020100).all()
+
+
+def test_chain_over_utterances_exact_kernel(orc_en, means_en, monkeypatch):
+    """the same chain through the sequential kernel (SSW_PTM_EXACT=1, what ds != 1 uses)"""
+    import soundswallower_amd as ssw
+    feats, off = _ring_features(orc_en, means_en, 900)
+    want = orc_en.ptm_score_chain(feats, off)
+    monkeypatch.setenv("SSW_PTM_EXACT", "1")
+    m = ssw.Model(ssw.model_dir("en-us"))
+    monkeypatch.delenv("SSW_PTM_EXACT")
+    got, _ = m.score_batch_carry(feats, off, carry_utts=True, rewind=True)
+    assert np.array_equal(got, want)
+    cut = int(off[8])
+    a, c1 = m.score_batch_carry(feats[:cut], off[:9], carry_utts=True, rewind=True)
+    b, _ = m.score_batch_carry(feats[cut:], off[8:] - cut, carry_in=c1, carry_utts=True)
+    assert np.array_equal(np.concatenate([a, b]), want)

@@ -63,46 +63,64 @@ def test_second_pass_scored_from_the_first_pass_history(gpu_en, orc_en, oracle_m
     cand = (np.round(synth_features(means_en, 600, 31337) * 8.0) / 8.0).astype(np.float32)
     real = np.concatenate([cand[578:579], plain_audio, cand[169:170]]).astype(np.float32)
     coarse = np.concatenate([cand[538:539], plain_audio, cand[461:462]]).astype(np.float32)
+    # the history is a ring of two slots indexed by frame % 2 (src/ptm_mgau.c:425-437),
+    # and after the rewind frame 0 copies slot 1 = the last ODD-numbered frame of the first pass.
+    # `real` and `coarse` have an even number of frames (that is their last frame); `odd` has one
+    # more frame behind y, which the second pass must NOT start from.
+    odd = np.concatenate([real, plain_audio[100:101]]).astype(np.float32)
     n = len(real)
+    assert n % 2 == 0 and len(odd) % 2 == 1
     lex = _lex(gpu_en, "en-us")
     want, n_differ = [], []
-    for feats in (real, coarse):
-        scr1, carry = gpu_en.score_batch_carry(feats)                    # reset history
+    for feats in (real, coarse, odd):
+        scr1, carry = gpu_en.score_batch_carry(feats, rewind=True)       # reset history
         scr2, _ = gpu_en.score_batch_carry(feats, carry_in=carry)        # from what pass 1 left
         orc_en.ptm_reset()
         assert np.array_equal(scr2, two_pass_scores(orc_en, feats))      # the reference's second scoring
         n_differ.append(int((scr1 != scr2).any(axis=1).sum()))
-        want.append(_second_pass(gpu_en, lex, scr1, scr2, n))
+        want.append(_second_pass(gpu_en, lex, scr1, scr2, len(feats)))
     orc_en.ptm_reset()
-    assert n_differ[0] >= 1 and n_differ[1] >= 1, n_differ   # the flag has something to change
-    batch = np.concatenate([real, coarse, real[:40]])
-    off = np.array([0, n, 2 * n, 2 * n + 40], np.int32)
+    assert min(n_differ) >= 1, n_differ                     # the flag has something to change
+    # the odd utterance from its LAST frame's order (round 3's rule) is not the reference's scoring
+    _, last = gpu_en.score_batch_carry(odd)
+    wrong, _ = gpu_en.score_batch_carry(odd, carry_in=last)
+    orc_en.ptm_reset()
+    assert not np.array_equal(wrong, two_pass_scores(orc_en, odd))
+    orc_en.ptm_reset()
+    # a one-frame utterance never writes slot 1: its second pass starts where its first did
+    one = odd[:1]
+    _, c1 = gpu_en.score_batch_carry(one, rewind=True)
+    assert (c1 == 0x03020100).all()
+    batch = np.concatenate([real, coarse, real[:40], odd, one])
+    off = np.cumsum([0, n, n, 40, len(odd), 1]).astype(np.int32)
     d_feats = torch.from_numpy(batch).cuda()
-    texts = [TEXT, TEXT, TEXT]
+    texts = [TEXT] * 5
     cfg = lex.first_pass_config(two_pass_history=1)
     aset = ssw.align_text_batch(gpu_en, lex, d_feats, off, texts, cfg=cfg)
     plain = ssw.align_text_batch(gpu_en, lex, d_feats, off, texts)
     try:
         assert aset.status(2) == 1 and plain.status(2) == 1      # 40 frames cannot hold the text
+        assert aset.status(4) == 1 and plain.status(4) == 1      # nor can one
         differs_from_plain = False
-        for u in range(2):
+        for u, w in ((0, 0), (1, 1), (3, 2)):
             got = aset.utterance(u)
             assert got is not None
-            assert got["words"] == want[u][0]
-            assert np.array_equal(got["state_al"], want[u][1]), u
+            assert got["words"] == want[w][0]
+            assert np.array_equal(got["state_al"], want[w][1]), u
             differs_from_plain |= not np.array_equal(plain.utterance(u)["state_al"], got["state_al"])
         # (informational: whether the tie-dependent frames lie on the best path is up to the data)
         print("two-pass history changed a state alignment:", differs_from_plain, n_differ)
     finally:
         aset.free()
         plain.free()
-    # The same utterances 20 times over in one batch (5.6 K frames: the matrix-core scan), scored in
+    # The same utterances 7 times over in one batch (5.9 K frames: the matrix-core scan), scored in
     # pieces of 1024 frames: every utterance's second pass must start from ITS OWN first pass's
     # last order (a row per utterance on the device), wherever the piece edges fall
     import os
-    reps = 20
-    big = np.concatenate([real, coarse] * (reps // 2))
-    boff = (np.arange(reps + 1) * n).astype(np.int32)
+    reps = 21
+    seq = [real, coarse, odd] * (reps // 3)
+    big = np.concatenate(seq)
+    boff = np.cumsum([0] + [len(a) for a in seq]).astype(np.int32)
     os.environ["SSW_SCORE_PIECE"] = "1024"
     try:
         bset = ssw.align_text_batch(gpu_en, lex, torch.from_numpy(big).cuda(), boff, [TEXT] * reps,
@@ -112,8 +130,8 @@ def test_second_pass_scored_from_the_first_pass_history(gpu_en, orc_en, oracle_m
     try:
         for u in range(reps):
             got = bset.utterance(u)
-            assert got is not None and got["words"] == want[u % 2][0], u
-            assert np.array_equal(got["state_al"], want[u % 2][1]), u
+            assert got is not None and got["words"] == want[u % 3][0], u
+            assert np.array_equal(got["state_al"], want[u % 3][1]), u
     finally:
         bset.free()
         lex.free()

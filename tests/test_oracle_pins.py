@@ -249,3 +249,25 @@ def test_state_align_word_constraints(orc_en):
     rv, st, ph = orc_en.state_align(scr, senid, tmat, sf=sf, ef=ef)
     assert rv == 0
     assert ph[3, 0] == 30  # the second "word" starts exactly at its constraint
+
+
+def test_chain_of_utterances_reads_history_slot_one(orc_en, means_en):
+    """The scorer's history is a ring of two slots indexed by frame % 2 and frame numbers restart
+    with every utterance (src/ptm_mgau.c:425-437, src/acmod.c:367): frame 0 of an utterance copies
+    slot 1, the last odd-numbered frame before it.  Checked on the oracle by an independent route:
+    behind an utterance of odd length T the next one scores as if it followed the first T - 1
+    frames directly; behind an even one, as if the two were one utterance."""
+    from tests.test_gpu_ptm import _ring_features
+    feats, off = _ring_features(orc_en, means_en, 420)
+    chain = orc_en.ptm_score_chain(feats, off)
+    one = orc_en.ptm_score_utt(feats)
+    assert (chain != one).any(axis=1).sum() >= 6          # the ring shows on this input
+    # independent route: drop every frame that is off the chain (the last frame of an utterance
+    # of odd length), score what is left as ONE utterance -- frame t then follows frame t - 1 --
+    # and compare the frames that were kept
+    keep = np.ones(len(feats), bool)
+    for u in range(len(off) - 1):
+        if (off[u + 1] - off[u]) % 2:
+            keep[off[u + 1] - 1] = False
+    direct = orc_en.ptm_score_utt(feats[keep])
+    assert np.array_equal(chain[keep], direct)
