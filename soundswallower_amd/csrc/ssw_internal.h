@@ -23,8 +23,8 @@ extern "C" {
 #define SSW_MAX_VECLEN 15
 /* per codebook-stream: [0] count, [1..] codewords the quadratic scan leaves to the exact form */
 #define SSW_EXLIST_STRIDE 132
-/* bf16 MFMA scan: bf16 values per (codebook, stream) in wfrag */
-#define SSW_WFRAG_PER_CBF (4 * 2 * 3 * 64 * 8)
+/* matrix-core scan: binary16 values per (codebook, stream) in wfrag */
+#define SSW_WFRAG_PER_CBF (4 * 2 * 2 * 64 * 8)
 
 /* Host-side model: every table derived exactly as the reference derives it. */
 typedef struct ssw_host_model_s {
@@ -36,15 +36,19 @@ typedef struct ssw_host_model_s {
     /* device-layout Gaussian tables (ssw_host_build_records):
      *   rec     [cb*feat][density][32]  exact records (mean, det, scale)
      *   recq    [cb*feat][density][32]  quadratic-form scan records (a, c, b)
-     *   recd0   [cb*feat][32]           [0] = the codebook's reference det d0
+     *   recd0   [cb*feat][32]           [0] = the codebook's reference det d0; matrix-core
+     *                                   scan: [1] = 2^s, [2] = 2^-s (its keys are key 2^-s),
+     *                                   [3] = 2^ec (the constant's slot of X)
      *   exlist  [cb*feat][SSW_EXLIST_STRIDE] */
     float *rec, *recq, *recd0;
     uint32_t *exlist;
     int32_t n_exact_form;
     /* the same scan for the matrix cores (ssw_k1a_mfma.inc): quadratic-form records whose
-     * constant carries the error bound of the split-bf16 MFMA evaluation (recqm, exlistm as
-     * recq / exlist), and the records cut into three bf16 parts in MFMA A-fragment order:
-     *   wfrag [cb*feat][4 row blocks][2 K blocks][3 parts][64 lanes][8] bf16
+     * constant carries the error bound of the split-binary16 MFMA evaluation (recqm, exlistm as
+     * recq / exlist; recqm's constant is what its two parts add up to, unscaled), and the
+     * records, scaled by 2^-s (the constant by 2^-(s + ec)), cut into two binary16 parts in MFMA
+     * A-fragment order:
+     *   wfrag [cb*feat][4 row blocks][2 K blocks][2 parts][64 lanes][8] binary16
      * (lane l of a fragment: density 32*rb + l%32, K = 16*kb + 8*(l/32) .. +7) */
     float *recqm;
     uint32_t *exlistm;

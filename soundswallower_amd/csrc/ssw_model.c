@@ -757,76 +757,178 @@ cmp_float(const void *a, const void *b)
  * and go on the codebook's exact-form list: the kernel evaluates them the reference's
  * way after the scan.  tests/test_scan_bound.py replays the kernel's arithmetic on the
  * CPU against these tables. */
-/* round-to-nearest-even float -> bf16 (as v_cvt_pk_bf16_f32 does for finite values) */
+/* round-to-nearest-even float -> IEEE binary16, subnormals kept, overflow to infinity: what
+ * v_cvt_pk_f16_f32 does with the kernels' default mode (tools/microbench/mfma_f16_scan.hip
+ * compares the two on values down to 2^-40) */
 static uint16_t
-bf16_rne(float x)
+f16_rne(float x)
 {
-    uint32_t u;
+    uint32_t u, sign, mant;
+    int e;
     memcpy(&u, &x, 4);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-
-static float
-bf16_to_float(uint16_t b)
-{
-    uint32_t u = (uint32_t)b << 16;
-    float x;
-    memcpy(&x, &u, 4);
-    return x;
-}
-
-/* x = p[0] + p[1] + p[2] + r with |r| <= 2^-24 |x|: three bf16 parts of a float; the residuals
- * x - p[0] and x - p[0] - p[1] are exact in float arithmetic */
-static void
-bf16_split3(float x, uint16_t p[3])
-{
-    float r = x;
-    int i;
-    for (i = 0; i < 3; ++i) {
-        p[i] = bf16_rne(r);
-        r = r - bf16_to_float(p[i]);
+    sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u >= 0x7f800000u) /* inf / nan */
+        return (uint16_t)(sign | 0x7c00u | (u > 0x7f800000u ? 0x200u : 0u));
+    e = (int)(u >> 23) - 127;
+    mant = (u & 0x7fffffu) | 0x800000u; /* 24 bits, value = mant 2^(e - 23) */
+    if (e >= 16)
+        return (uint16_t)(sign | 0x7c00u);
+    if (e >= -14) { /* normal: keep 11 bits */
+        uint32_t keep = mant >> 13, rest = mant & 0x1fffu;
+        uint32_t h = ((uint32_t)(e + 15) << 10) + (keep & 0x3ffu);
+        if (rest > 0x1000u || (rest == 0x1000u && (keep & 1u)))
+            ++h; /* may carry into the exponent, up to infinity: correct */
+        return (uint16_t)(sign | h);
+    }
+    if (e < -26) /* below half of the smallest subnormal (2^-25): zero */
+        return (uint16_t)sign;
+    {
+        /* subnormal: value = q 2^-24, q = mant 2^(e + 1) rounded */
+        const int shift = -1 - e; /* 14 .. 25 */
+        uint32_t q = mant >> shift, rest = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rest > half || (rest == half && (q & 1u)))
+            ++q;
+        return (uint16_t)(sign | q);
     }
 }
 
+static float
+f16_to_float(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const int e = (h >> 10) & 0x1f;
+    const uint32_t m = h & 0x3ffu;
+    float x;
+    if (e == 0)
+        x = ldexpf((float)m, -24);
+    else if (e == 31)
+        x = m ? NAN : INFINITY;
+    else
+        x = ldexpf((float)(m | 0x400u), e - 25);
+    return sign ? -x : x;
+}
+
+/* x = p[0] + p[1] + r: two binary16 parts of a float, the first residual x - p[0] exact in float
+ * arithmetic; |r| <= max(2^-22 |x|, 2^-25) while the parts stay finite */
+static void
+f16_split2(float x, uint16_t p[2])
+{
+    p[0] = f16_rne(x);
+    p[1] = f16_rne(x - f16_to_float(p[0]));
+}
+
 /* Scan records for the matrix-core scan (csrc/ssw_k1a_mfma.inc).  The key of density i for
- * frame x is the same quadratic form c + sum_j (a_j x_j + b_j x_j^2) as in recq, but W = (a, c, b)
- * and X = (x, 1, x^2) are cut into three bf16 parts each and the six largest part products
- * (1,1) (1,2) (2,1) (2,2) (1,3) (3,1) are accumulated by v_mfma_f32_32x32x16_bf16 in fp32.
- * With u = 2^-24 and M = sum_k |W_k X_k| the key differs from the real number by at most
- *     u M      x^2 rounded to fp32 before the split
- *   + u M      residuals of the two splits (three round-to-nearest bf16 parts leave 2^-27) and
- *              the three part products left out ((2,3) (3,2) (3,3): 2^-25 M together)
- *   + the accumulation error of the twelve chained MFMAs.  Every product of two bf16 values is
- *     exact in fp32, so MFMA i returns the exact sum of its 16 products and its C input up to
- *     e_i <= eps (m_i + |C_i|), m_i = the sum of the |products| it adds.  The chain adds the
- *     smallest products first: six MFMAs of (1,3) (3,1) (2,2) products (m_i <= 2^-16 M_kb), four
- *     of (1,2) (2,1) products (m_i <= 2^-8 (1 + 2^-8) M_kb), then the (1,1) products of K block
- *     0 and of K block 1 (m_i <= M_0, M_1; M_0 + M_1 = M).  |C_i| <= sum_{j<i} m_j (1 + eps)^i,
- *     so  sum e_i <= eps sum_j m_j (1 + number of MFMAs after j)
- *                 <= eps (12 * 3 * 2^-16 + 6 * 2 * 2^-8 * 1.004 + 2) M  <=  2.05 eps M:
- *     only the last two MFMAs see terms of the size of M (round 2 charged all thirteen steps
- *     with eps M and needed K = 119 for eps = 8 u).
- * eps itself is not documented for v_mfma_f32_32x32x16_bf16.  Two models cover what a
- * 17-term fp32 adder can do: (A) the terms are added one after the other, in any order, each
- * addition rounded OR truncated to fp32: error <= 16 * 2^-23 = 32 u of sum |terms|; (B) the terms
- * are aligned to the largest exponent, truncated to a 24-bit grid, summed exactly and rounded
- * once: 16 * 2 u + 2 u = 34 u.  eps <= 34 u is assumed -- eight times the worst value
- * tools/microbench/mfma_bf16_scan.hip measures on cancelling data (4.3 u), where round 2 had a
- * factor below two -- which gives 2 u + 2.05 * 34 u = 71.7 u, taken as K u M with K = 80.
+ * frame x is the same quadratic form c + sum_j (a_j x_j + b_j x_j^2) as in recq.
+ *
+ * Round 4: W = (a, c, b) and X = (x, 1, x^2) are cut into TWO binary16 parts each (2 x 11 = 22
+ * significand bits) and the three part products (1,1) (1,2) (2,1) are accumulated by six
+ * v_mfma_f32_32x32x16_f16 per 32 x 32 tile -- rounds 2-3 used three bf16 parts and six part
+ * products, twelve MFMAs, for the same error constant.  binary16 has a narrow exponent range, so
+ * the rows of a codebook x stream are scaled by one power of two, W' = W 2^-s (its keys come out
+ * as key 2^-s: only keys of one codebook x stream are ever compared, and the kernel scales the
+ * one key it uses as a bound back), and the constant travels as c' = c 2^-s 2^-ec against
+ * X = 2^ec.  The kernel refuses the speculative result of a frame with |x_j| > 255 (x_j^2 would
+ * not fit binary16): such a frame takes the exact pass.
+ *
+ * Error of the evaluated key against the real number, in units of u = 2^-24, with
+ * M = sum_k |W_k X_k| (all of it scales with 2^-s, so the analysis is the unscaled one):
+ *   (a) x^2 rounded to fp32 before the split:                          1 u M
+ *   (b) what the three products leave out: W X - (W1 X1 + W1 X2 + W2 X1) = W2 X2 + (W1 + W2) Xr
+ *       + Wr X with Xr, Wr the residuals of the two-part splits.  |W2| <= 2^-11 |W|, |X2| <=
+ *       2^-11 |X|: 4 u M; |Xr| <= max(2^-22 |X|, 2^-25) (binary16 subnormals are honoured by the
+ *       conversion and by the matrix pipe, tools/microbench/mfma_f16_scan.hip): 4 u M plus the
+ *       CONSTANT 2^-25 sum_k |W'_k| 2^s; Wr is known here exactly, element by element: an
+ *       element whose |Wr_k| Xmax_k (Xmax = 255, 255^2, 2^ec) stays below 0.02 score units is
+ *       charged that constant, the others relatively, rho = max_k |Wr_k| / |W_k| (2^-22 = 4 u
+ *       when both parts of the element are normal numbers):                (8.01 u + rho) M
+ *   (c) the accumulation error of the six chained MFMAs.  Every product of two binary16 values
+ *       is exact in fp32 (22 bits), so MFMA i returns the exact sum of its 16 products and its C
+ *       input up to e_i <= eps (m_i + |C_i|), m_i = the sum of the |products| it adds.  The chain
+ *       adds the small products first -- (1,2) and (2,1) of both K blocks, m_i <= 2^-11 M_kb
+ *       (1 + 2^-11) -- then the (1,1) products of K block 0 and of K block 1 (M_0 + M_1 = M);
+ *       |C_i| <= sum_{j<i} m_j (1 + eps)^i, so  sum e_i <= eps sum_j m_j (1 + number of MFMAs
+ *       after j) <= eps (2 + 6 * 2 * 2^-11 * 1.001) M <= 2.01 eps M.
+ *       eps itself is not documented for v_mfma_f32_32x32x16_f16.  Two models cover what a
+ *       17-term fp32 adder can do: (A) the terms are added one after the other, in any order,
+ *       each addition rounded OR truncated to fp32: error <= 16 * 2^-23 = 32 u of sum |terms|;
+ *       (B) the terms are aligned to the largest exponent, truncated to a 24-bit grid, summed
+ *       exactly and rounded once: 16 * 2 u + 2 u = 34 u.  eps <= 34 u is assumed -- 6.5 times
+ *       the worst value tools/microbench/mfma_f16_scan.hip measures on cancelling data
+ *       (5.2 u):                                                           68.4 u M
+ *   (d) a = 2 var mean rounded to fp32 (b = -var is exact; c is rounded UP to a value its two
+ *       parts represent exactly, below):                                    1 u M
+ * Together K_i u M with K_i = 79 + rho_i / u per density (78.4 rounded up; 83 when every element
+ * keeps both parts normal); a density whose K_i would pass SSW_MFMA_K = 96 goes on the
+ * exact-form list.  An inert row is a = b = 0 with -65504 in the two spare K slots 13 and 14,
+ * which X holds at 32768: key' = -4.3e9.
  * tests/test_gpu_mfma_bound.py checks the resulting bound on the device on stress inputs and on
  * inputs built to cancel (x = 2 mean: every a_j x_j + b_j x_j^2 pair cancels, M is 8 R while the
- * value is det - R), and tests/test_gpu_scan_agreement.py that the matrix-core scan and the
- * vector-unit scan (whose bound IS replayed on the CPU, tests/test_scan_bound.py) give
- * identical top-N blocks.
+ * value is det - R), tests/test_scan_bound.py replays (a) and (b) exactly on the CPU (everything
+ * but the adder), and tests/test_gpu_scan_agreement.py checks that the matrix-core scan and the
+ * vector-unit scan (whose bound IS replayed on the CPU in full) give identical top-N blocks.
  * The reference's own fp32 value is within 13 u |det| + 17 u S of the real number, and
  * M <= |det - d0| + 6 R + 3 S, S <= |det - d0| + |value - d0| as for recq, which gives the
- * per-density constant (4K + 17) |det - d0| + 6K R + 13 |det| folded into c below (with slack)
- * and the term (3K + 17) u |value - d0| the kernel adds to the one key it uses as a bound.
- * Densities whose constant exceeds SSW_MFMA_MAX_BIAS score units keep an inert record and are
- * evaluated in the exact form (exlistm). */
-#define SSW_MFMA_K 80.0
+ * per-density constant (4 K_i + 17) |det - d0| + 6 K_i R + 13 |det| (in u) folded into c below
+ * with the constants of (b), with slack, and the term (3 K + 17) u |value - d0| the kernel adds
+ * (with K = SSW_MFMA_K) to the one key it uses as a bound.  Densities whose constant exceeds
+ * SSW_MFMA_MAX_BIAS score units keep an inert record and are evaluated in the exact form
+ * (exlistm); so is a density that alone forces a scale s at which others lose their second part
+ * (a floored variance of 5e7 next to variances of 2). */
+#define SSW_MFMA_K 96.0
+#define SSW_MFMA_K0 79.0
 #define SSW_MFMA_MAX_BIAS 64.0
+#define SSW_MFMA_XMAX 255.0
+#define SSW_MFMA_ABS_UNIT 0.02
+
+/* the K index of MFMA operand slot k (record float slot): 0..12 a | 15 c | 16..28 b */
+static double
+mfma_slot_xmax(int k, double xconst)
+{
+    if (k < SSW_MAX_VECLEN)
+        return SSW_MFMA_XMAX;
+    if (k == SSW_REC_DET)
+        return xconst;
+    return SSW_MFMA_XMAX * SSW_MFMA_XMAX;
+}
+
+/* One density under scale 2^-s (and 2^-ec on the constant): its error constant K_i, the additive
+ * constant of (b) in score units, and whether every scaled element stays finite in binary16.
+ * q = the unscaled record (a, c WITHOUT bias, b). */
+static int
+mfma_density_terms(const double *q, int s, int ec, double *K_i, double *add)
+{
+    const double u24 = 1.0 / 16777216.0, scale = ldexp(1.0, s);
+    double rho = 0.0, cst = 0.0, sumw = 0.0;
+    int k;
+    for (k = 0; k < SSW_REC_FLOATS; ++k) {
+        uint16_t p[2];
+        double w, wr;
+        float wf;
+        if (q[k] == 0.0)
+            continue;
+        wf = (float)ldexp(q[k], -(s + (k == SSW_REC_DET ? ec : 0)));
+        if (!(fabsf(wf) <= 32768.0f))
+            return -1;
+        if (k == SSW_REC_DET) /* the constant is rounded up to what its parts represent: no error */
+            continue;
+        f16_split2(wf, p);
+        w = (double)wf;
+        wr = fabs(w - ((double)f16_to_float(p[0]) + (double)f16_to_float(p[1])));
+        /* (the float rounding of the scaled element itself: q 2^-s is exact unless q 2^-s is a
+         * float subnormal, which |q| >= 2^-100 rules out for every sane model) */
+        if (wr * mfma_slot_xmax(k, 0.0) * scale <= SSW_MFMA_ABS_UNIT)
+            cst += wr * mfma_slot_xmax(k, 0.0) * scale;
+        else if (wr / fabs(w) > rho)
+            rho = wr / fabs(w);
+        sumw += fabs(w); /* X residual below the binary16 grid: 2^-25 per element */
+    }
+    cst += ldexp(sumw, -25) * scale;
+    *K_i = SSW_MFMA_K0 + rho / u24;
+    *add = cst;
+    return 0;
+}
+
 static int
 ssw_host_build_mfma_records(ssw_host_model_t *h)
 {
@@ -834,6 +936,9 @@ ssw_host_build_mfma_records(ssw_host_model_t *h)
     const size_t nrec = (size_t)ncbf * h->n_density;
     const double u24 = 1.0 / 16777216.0;
     int cbf, d, j, rb, kb, p, l, e;
+    double *qd;       /* [n_density][SSW_REC_FLOATS] unscaled a, c (no bias), b of one cbf */
+    double *geo;      /* [n_density][4]: delta, R, det, max |a|,|b| */
+    unsigned char *inert;
 
     h->recqm = NULL;
     h->exlistm = NULL;
@@ -844,60 +949,215 @@ ssw_host_build_mfma_records(ssw_host_model_t *h)
     h->recqm = (float *)calloc(nrec * SSW_REC_FLOATS, sizeof(float));
     h->exlistm = (uint32_t *)calloc((size_t)ncbf * SSW_EXLIST_STRIDE, sizeof(uint32_t));
     h->wfrag = (uint16_t *)calloc((size_t)ncbf * SSW_WFRAG_PER_CBF, sizeof(uint16_t));
-    if (!h->recqm || !h->exlistm || !h->wfrag) {
+    qd = (double *)calloc((size_t)h->n_density * SSW_REC_FLOATS, sizeof(double));
+    geo = (double *)calloc((size_t)h->n_density * 4, sizeof(double));
+    inert = (unsigned char *)calloc((size_t)h->n_density, 1);
+    if (!h->recqm || !h->exlistm || !h->wfrag || !qd || !geo || !inert) {
+        free(qd);
+        free(geo);
+        free(inert);
         ssw_set_error("out of memory building the MFMA scan records");
         return -1;
     }
     for (cbf = 0; cbf < ncbf; ++cbf) {
         uint32_t *xl = h->exlistm + (size_t)cbf * SSW_EXLIST_STRIDE;
-        const float d0 = h->recd0[(size_t)cbf * SSW_REC_FLOATS];
+        float *d0rec = h->recd0 + (size_t)cbf * SSW_REC_FLOATS;
+        const float d0 = d0rec[0];
+        int s = 0, ec = 0, round;
+        memset(inert, 0, (size_t)h->n_density);
+        memset(qd, 0, sizeof(double) * (size_t)h->n_density * SSW_REC_FLOATS);
         for (d = 0; d < h->n_density; ++d) {
             const float *r = h->rec + ((size_t)cbf * h->n_density + d) * SSW_REC_FLOATS;
-            float *q = h->recqm + ((size_t)cbf * h->n_density + d) * SSW_REC_FLOATS;
+            double *q = qd + (size_t)d * SSW_REC_FLOATS, *g = geo + (size_t)d * 4;
             const double det = r[SSW_REC_DET], delta = det - (double)d0;
-            double R = 0.0, bias, cc;
+            double R = 0.0, mw = 0.0, bias0;
             int finite = isfinite(det);
-            float cf;
             for (j = 0; j < SSW_MAX_VECLEN; ++j) {
                 double mean = r[j], var = r[SSW_REC_VAR + j];
                 R += fabs(var) * mean * mean;
                 finite = finite && isfinite(mean) && isfinite(var) && var >= 0.0;
+                /* (as floats: these are the values whose parts the matrix cores multiply) */
+                q[j] = (double)(float)(2.0 * var * mean);
+                q[SSW_REC_VAR + j] = (double)(float)(-var);
+                if (fabs(q[j]) > mw)
+                    mw = fabs(q[j]);
+                if (fabs(q[SSW_REC_VAR + j]) > mw)
+                    mw = fabs(q[SSW_REC_VAR + j]);
             }
-            bias = 1.05 * u24
-                * ((4.0 * SSW_MFMA_K + 18.0) * fabs(delta) + (6.0 * SSW_MFMA_K + 2.0) * R
+            g[0] = delta, g[1] = R, g[2] = det, g[3] = mw;
+            /* intrinsically too ill-conditioned for the scan whatever the scale */
+            bias0 = 1.05 * u24
+                * ((4.0 * SSW_MFMA_K0 + 18.0) * fabs(delta) + (6.0 * SSW_MFMA_K0 + 2.0) * R
                    + 14.0 * fabs(det));
-            if (!finite || !(bias <= SSW_MFMA_MAX_BIAS)) {
+            if (!finite || !(bias0 <= SSW_MFMA_MAX_BIAS) || !(mw < 1.0e30))
+                inert[d] = 1;
+        }
+        /* the scale: the largest |a|, |b| of the live densities just fits 2^15; a density that
+         * fails at that scale only because of its lost second parts is what the scale-setter
+         * costs, and the scale-setter goes on the exact-form list instead */
+        for (round = 0; round <= h->n_density; ++round) {
+            double mw = 0.0, mc = 0.0;
+            int setter = -1, n_fail = 0;
+            for (d = 0; d < h->n_density; ++d)
+                if (!inert[d]) {
+                    const double *g = geo + (size_t)d * 4;
+                    if (g[3] > mw) {
+                        mw = g[3];
+                        setter = d;
+                    }
+                    /* |c| <= |delta| + R + bias */
+                    if (fabs(g[0]) + g[1] + SSW_MFMA_MAX_BIAS > mc)
+                        mc = fabs(g[0]) + g[1] + SSW_MFMA_MAX_BIAS;
+                }
+            s = 0;
+            if (mw > 0.0) {
+                (void)frexp(mw / 32768.0, &s); /* mw / 32768 = f 2^s, f in [0.5, 1): mw 2^-s <= 32768 */
+                if (s < -8)
+                    s = -8;
+            }
+            ec = 0;
+            if (mc > 0.0) {
+                (void)frexp(ldexp(mc, -s) / 32768.0, &ec);
+                if (ec < 0)
+                    ec = 0;
+                if (ec > 15)
+                    ec = 15;
+            }
+            for (d = 0; d < h->n_density; ++d)
+                if (!inert[d]) {
+                    const double *g = geo + (size_t)d * 4;
+                    double *q = qd + (size_t)d * SSW_REC_FLOATS;
+                    double K_i, add, bias;
+                    q[SSW_REC_DET] = g[0] - g[1]; /* c without its bias */
+                    if (mfma_density_terms(q, s, ec, &K_i, &add) < 0 || K_i > SSW_MFMA_K) {
+                        ++n_fail;
+                        continue;
+                    }
+                    bias = 1.05
+                        * (u24
+                               * ((4.0 * K_i + 18.0) * fabs(g[0]) + (6.0 * K_i + 2.0) * g[1]
+                                  + 14.0 * fabs(g[2]))
+                           + add);
+                    if (!(bias <= SSW_MFMA_MAX_BIAS))
+                        ++n_fail;
+                }
+            if (n_fail == 0 || setter < 0)
+                break;
+            /* would the others pass without the scale-setter?  Try: drop it and look again; when
+             * the scale cannot shrink any more (s at its floor) the failures are their own */
+            {
+                double next = 0.0;
+                int s2 = 0;
+                for (d = 0; d < h->n_density; ++d)
+                    if (!inert[d] && d != setter && geo[(size_t)d * 4 + 3] > next)
+                        next = geo[(size_t)d * 4 + 3];
+                if (next > 0.0)
+                    (void)frexp(next / 32768.0, &s2);
+                if (next > 0.0 && s2 < s && s > -8) {
+                    inert[setter] = 1;
+                    continue;
+                }
+            }
+            /* the scale is not to blame: the failing densities go on the list themselves */
+            for (d = 0; d < h->n_density; ++d)
+                if (!inert[d]) {
+                    const double *g = geo + (size_t)d * 4;
+                    double *q = qd + (size_t)d * SSW_REC_FLOATS;
+                    double K_i, add, bias;
+                    q[SSW_REC_DET] = g[0] - g[1];
+                    if (mfma_density_terms(q, s, ec, &K_i, &add) < 0 || K_i > SSW_MFMA_K) {
+                        inert[d] = 1;
+                        continue;
+                    }
+                    bias = 1.05
+                        * (u24
+                               * ((4.0 * K_i + 18.0) * fabs(g[0]) + (6.0 * K_i + 2.0) * g[1]
+                                  + 14.0 * fabs(g[2]))
+                           + add);
+                    if (!(bias <= SSW_MFMA_MAX_BIAS))
+                        inert[d] = 1;
+                }
+            /* (the scale may now be larger than the survivors need: one more look) */
+        }
+        d0rec[1] = (float)ldexp(1.0, s);   /* key = key' * this */
+        d0rec[2] = (float)ldexp(1.0, -s);  /* key' = key * this (exact-form densities) */
+        d0rec[3] = (float)ldexp(1.0, ec);  /* the constant's slot of X */
+        for (d = 0; d < h->n_density; ++d) {
+            float *q = h->recqm + ((size_t)cbf * h->n_density + d) * SSW_REC_FLOATS;
+            const double *g = geo + (size_t)d * 4;
+            double *qq = qd + (size_t)d * SSW_REC_FLOATS;
+            double K_i = 0.0, add = 0.0, bias, cc;
+            float cf;
+            if (!inert[d]) {
+                qq[SSW_REC_DET] = g[0] - g[1];
+                if (mfma_density_terms(qq, s, ec, &K_i, &add) < 0 || K_i > SSW_MFMA_K)
+                    inert[d] = 1; /* (cannot happen after the loop above; kept as a guard) */
+            }
+            if (inert[d]) {
                 xl[1 + xl[0]++] = (uint32_t)d;
                 q[SSW_REC_DET] = -3.0e38f; /* a = b = 0: the key stays out of the way */
                 ++h->n_exact_form_m;
                 continue;
             }
+            bias = 1.05
+                * (u24
+                       * ((4.0 * K_i + 18.0) * fabs(g[0]) + (6.0 * K_i + 2.0) * g[1]
+                          + 14.0 * fabs(g[2]))
+                   + add);
             for (j = 0; j < SSW_MAX_VECLEN; ++j) {
-                q[j] = (float)(2.0 * (double)r[SSW_REC_VAR + j] * (double)r[j]);
-                q[SSW_REC_VAR + j] = -r[SSW_REC_VAR + j];
+                q[j] = (float)qq[j];
+                q[SSW_REC_VAR + j] = (float)qq[SSW_REC_VAR + j];
             }
-            cc = delta - R + bias;
-            cf = (float)cc;
-            if ((double)cf < cc)
-                cf = nextafterf(cf, INFINITY);
-            q[SSW_REC_DET] = cf;
+            cc = g[0] - g[1] + bias;
+            /* the constant as the matrix cores will see it: scaled, cut in two parts, rounded
+             * UP where the cut loses something */
+            {
+                uint16_t pp[2];
+                float cs = (float)ldexp(cc, -(s + ec));
+                double back;
+                int tries;
+                if ((double)cs < ldexp(cc, -(s + ec)))
+                    cs = nextafterf(cs, INFINITY);
+                for (tries = 0; tries < 64; ++tries) {
+                    f16_split2(cs, pp);
+                    back = (double)f16_to_float(pp[0]) + (double)f16_to_float(pp[1]);
+                    if (back >= ldexp(cc, -(s + ec)))
+                        break;
+                    cs = nextafterf(cs, INFINITY);
+                }
+                cf = (float)ldexp(back, s + ec);
+                if ((double)cf < ldexp(back, s + ec))
+                    cf = nextafterf(cf, INFINITY);
+                q[SSW_REC_DET] = cf; /* what the two parts add up to, unscaled (for the tests) */
+                qq[SSW_REC_DET] = back; /* scaled by 2^-(s + ec): what goes into the fragments */
+            }
         }
         /* A fragments: K index k of the MFMA = float slot k of the record (a at 0..12, c at 15
-         * against X = 1, b at 16..28 against x^2; the other slots are zero on both sides) */
+         * against X = 2^ec, b at 16..28 against x^2; the other slots are zero on both sides) */
         for (rb = 0; rb < 4; ++rb)
             for (kb = 0; kb < 2; ++kb)
                 for (l = 0; l < 64; ++l)
                     for (e = 0; e < 8; ++e) {
                         const int dens = 32 * rb + (l & 31), k = 16 * kb + 8 * (l >> 5) + e;
-                        uint16_t parts[3];
-                        bf16_split3(h->recqm[((size_t)cbf * h->n_density + dens) * SSW_REC_FLOATS + k],
-                                    parts);
-                        for (p = 0; p < 3; ++p)
+                        const double *qq = qd + (size_t)dens * SSW_REC_FLOATS;
+                        uint16_t parts[2] = { 0, 0 };
+                        if (inert[dens]) {
+                            if (k == 13 || k == 14)
+                                parts[0] = 0xfbffu; /* -65504, against X = 32768 */
+                        } else {
+                            const float wf = k == SSW_REC_DET ? (float)qq[k]
+                                                               : (float)ldexp(qq[k], -s);
+                            f16_split2(wf, parts);
+                        }
+                        for (p = 0; p < 2; ++p)
                             h->wfrag[(size_t)cbf * SSW_WFRAG_PER_CBF
-                                     + ((((size_t)rb * 2 + kb) * 3 + p) * 64 + l) * 8 + e]
+                                     + ((((size_t)rb * 2 + kb) * 2 + p) * 64 + l) * 8 + e]
                                 = parts[p];
                     }
     }
+    free(qd);
+    free(geo);
+    free(inert);
     return 0;
 }
 

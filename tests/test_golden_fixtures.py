@@ -76,7 +76,7 @@ def test_gpu_matches_golden_config2_both_layouts(golden, gpu_en, means_en):
     {"SSW_SEN_FPB": "1"}, {"SSW_SEN_FPB": "4", "SSW_SEN_R": "2"}, {"SSW_SEN_FPB": "2", "SSW_SEN_R": "4"},
     {"SSW_SEN_FPB": "4", "SSW_SEN_R": "3"}, {"SSW_MFMA_STEPS": "2"}, {"SSW_SCAN": "fma"},
     {"SSW_SCAN": "fma", "SSW_SEN_FPB": "1", "SSW_SEN_R": "2"},
-    {"SSW_XSPLIT": "pre"}, {"SSW_SEN_GROUPS": "0"}, {"SSW_SEN_GROUPS": "300"},
+    {"SSW_SEN_GROUPS": "0"}, {"SSW_SEN_GROUPS": "300"},
     {"SSW_SCORE_PIECE": "1024"}, {"SSW_SCORE_PIECE": "768", "SSW_SEN_FPB": "1"},
     {"SSW_SEN_GENERIC": "1"}, {"SSW_SEN_GENERIC": "1", "SSW_SEN_FPB": "1"},
     {"SSW_SEN_GENERIC": "1", "SSW_SEN_FPB": "4", "SSW_SEN_R": "2"}])

@@ -446,3 +446,38 @@ def test_chain_over_utterances_exact_kernel(orc_en, means_en, monkeypatch):
     a, c1 = m.score_batch_carry(feats[:cut], off[:9], carry_utts=True, rewind=True)
     b, _ = m.score_batch_carry(feats[cut:], off[8:] - cut, carry_in=c1, carry_utts=True)
     assert np.array_equal(np.concatenate([a, b]), want)
+
+
+def test_features_beyond_the_binary16_range_take_the_exact_pass(gpu_en, orc_en, means_en):
+    """Round 4: the matrix-core scan cuts x and x^2 into binary16 parts, so a feature beyond
+    +-255 (its square does not fit) makes every key of its frame -inf or NaN; the kernel does not
+    trust such a frame and redoes it exactly -- with a floor for the exact scan only when the
+    four candidates are four different codewords.  Frames at, just below and far beyond the
+    limit, in single dimensions and all over, mixed into a batch large enough for the
+    matrix-core scan; scores and top-N order against the oracle, and only the frames that need it
+    (plus the usual handful) take the exact route."""
+    feats = np.concatenate([synth_features(means_en, 256, 4242 + i) for i in range(10)])
+    rng = np.random.default_rng(7)
+    hot = rng.choice(len(feats), 300, replace=False)
+    vals = [255.0, -255.0, 254.99, 255.01, 256.0, -300.0, 1000.0, 65504.0, 1.0e6, -3.0e9, 1.0e19]
+    beyond = np.zeros(len(feats), bool)
+    for i, t in enumerate(hot):
+        v = np.float32(vals[i % len(vals)])
+        if i % 3 == 0:                      # one dimension of one stream
+            feats[t, int(rng.integers(0, 39))] = v
+        elif i % 3 == 1:                    # the same dimension of every stream
+            feats[t, int(rng.integers(0, 13))::13] = v
+        else:                               # a whole stream scaled up
+            f = int(rng.integers(0, 3))
+            feats[t, 13 * f:13 * f + 13] *= np.float32(abs(v) / 8)
+        beyond[t] = np.abs(feats[t]).max() > 255.0
+    assert np.isfinite(feats).all() and beyond.sum() > 150
+    off = (np.arange(11) * 256).astype(np.int32)
+    got = gpu_en.score_batch(feats, off)
+    flagged, pairs = gpu_en.last_stats()
+    gcw, _ = gpu_en.last_topn(len(feats))
+    ref, rcw, _ = _oracle_batch(orc_en, feats, off)
+    assert np.array_equal(gcw.astype(np.int32), rcw)
+    assert np.array_equal(got, ref)
+    # a frame beyond the limit in one stream sends that stream's 42 pairs through the exact pass
+    assert beyond.sum() * 42 <= flagged <= beyond.sum() * 126 + pairs // 200

@@ -1,6 +1,6 @@
 """The two speculative scans against each other.  The vector-unit scan's
 error bound is replayed bit for bit on the CPU (tests/test_scan_bound.py); the matrix-core scan's
-rests on an assumed accumulation error of v_mfma_f32_32x32x16_bf16 (csrc/ssw_model.c).  A key
+rests on an assumed accumulation error of v_mfma_f32_32x32x16_f16 (csrc/ssw_model.c).  A key
 below the true density would drop a top-4 candidate -- the one failure the exact pass cannot
 catch -- and the two scans would then disagree.  So: the same batches through SSW_SCAN=fma and
 through the default (matrix cores), top-N codewords, raw scores and senone rows compared entry by
@@ -24,7 +24,13 @@ def _both(gpu, feats, monkeypatch, scorer=None):
     b = gpu.score_batch(feats, **kw)
     bcw, bsc = gpu.last_topn(len(feats))
     b_stats = gpu.last_stats()
-    assert np.array_equal(acw, bcw), "top-N codewords differ between the scans"
+    if not np.array_equal(acw, bcw):
+        bad = np.argwhere((acw != bcw).any(axis=3))
+        t, cb, f = (int(v) for v in bad[0])
+        x = np.asarray(feats, np.float32).reshape(len(acw), -1)[t, 13 * f:13 * f + 13]
+        raise AssertionError("top-N codewords differ between the scans: %d (frame, codebook, stream) "
+                             "entries, first at frame %d codebook %d stream %d (max |x| %.4g): %s / %s"
+                             % (len(bad), t, cb, f, float(np.abs(x).max()), acw[t, cb, f], bcw[t, cb, f]))
     assert np.array_equal(asc, bsc), "top-N scores differ between the scans"
     assert np.array_equal(a, b)
     return a_stats, b_stats

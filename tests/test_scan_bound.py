@@ -165,11 +165,53 @@ def test_scan_bound_on_a_hostile_model(oracle_mod, tmp_path):
         assert np.all(widen(k, d0[cbf]) >= r)
 
 
+MFMA_WIDEN = np.float32(1.8537045e-05)   # SSW_MFMA_WIDEN, csrc/ssw_k1a_mfma.inc (K = 96)
+MFMA_EPS = 34.0 * 2.0 ** -24             # the assumed accumulation error of one MFMA (ssw_model.c)
+
+
+def mfma_widen(key, d0):
+    """what ptm_topn_mfma_kernel does to the 5th key once it is back in score units"""
+    key = key.astype(np.float32)
+    ub = key + np.abs(key) * MFMA_WIDEN + np.float32(1.0e-3)
+    ub = ub + np.float32(d0)
+    return ub + np.abs(ub) * np.float32(2.384185791015625e-07)
+
+
+def mfma_operands(m, name=None):
+    """The matrix-core scan's tables as the kernel uses them: per codebook x stream the two
+    binary16 parts of W [128][32] (scaled by 2^-s, the constant by 2^-(s + ec)), 2^s and 2^ec."""
+    n_cbf = m.n_cb * m.n_feat
+    wf = m.table("scan_wfrag").reshape(n_cbf, 4, 2, 2, 64, 8).view(np.float16)
+    W = np.zeros((n_cbf, 2, 128, 32), np.float16)
+    for rb in range(4):
+        for kb in range(2):
+            for lane in range(64):
+                k0 = 16 * kb + 8 * (lane >> 5)
+                W[:, :, 32 * rb + (lane & 31), k0:k0 + 8] = wf[:, rb, kb, :, lane, :]
+    d0 = m.table("scan_d0").reshape(n_cbf, 32)
+    return W, d0[:, 0], d0[:, 1], d0[:, 3]
+
+
+def mfma_x_parts(x, xconst):
+    """mfma_build_x + split2_f16 in numpy: X = (x, 32768, 32768, 2^ec | fl(x^2), 0, 0, 0) cut
+    into two binary16 parts, the residual formed in float32 (exact)."""
+    n = len(x)
+    X = np.zeros((n, 32), np.float32)
+    X[:, 0:13] = x
+    X[:, 13] = X[:, 14] = 32768.0
+    X[:, 15] = xconst
+    X[:, 16:29] = x * x
+    with np.errstate(over="ignore"):
+        p1 = X.astype(np.float16)
+        p2 = (X - p1.astype(np.float32)).astype(np.float16)
+    return X, p1, p2
+
+
 def test_mfma_scan_records_are_consistent_with_the_fma_ones():
     """The matrix-core scan's tables (csrc/ssw_model.c, ssw_host_build_mfma_records): the same
-    quadratic form as SCAN_REC with a larger error constant; the three bf16 parts of every record
-    element add up to it exactly; exact-form densities have inert rows.  (That the resulting keys
-    bound the reference values is checked on the device: tests/test_gpu_mfma_bound.py.)"""
+    quadratic form as SCAN_REC with its own error constant; the two binary16 parts of every
+    record element add up to it within the split's residual (and the constant exactly: it is
+    rounded UP to what its parts represent); exact-form densities have inert rows."""
     for name in ("en-us", "fr-fr"):
         m = ssw.Model(os.path.join(MODEL_ROOT, name), config={"device": -2})
         n_cbf = m.n_cb * m.n_feat
@@ -177,24 +219,87 @@ def test_mfma_scan_records_are_consistent_with_the_fma_ones():
         rm = m.table("scan_rec_mfma").reshape(n_cbf, 128, 32)
         exq = m.table("scan_exact").reshape(n_cbf, 132)
         exm = m.table("scan_exact_mfma").reshape(n_cbf, 132)
-        wf = m.table("scan_wfrag").reshape(n_cbf, 4, 2, 3, 64, 8)
+        W, d0, scale, xconst = mfma_operands(m)
+        assert np.isfinite(W.astype(np.float32)).all()
         for cbf in range(n_cbf):
             live_q = np.ones(128, bool)
             live_q[exq[cbf, 1:1 + exq[cbf, 0]]] = False
             live_m = np.ones(128, bool)
             live_m[exm[cbf, 1:1 + exm[cbf, 0]]] = False
             both = live_q & live_m
-            # same a and b; a larger constant (more error to cover)
+            # same a and b as the vector-unit scan's records
             assert np.array_equal(rq[cbf, both][:, :13], rm[cbf, both][:, :13])
             assert np.array_equal(rq[cbf, both][:, 16:29], rm[cbf, both][:, 16:29])
-            assert (rm[cbf, both, 15] >= rq[cbf, both, 15]).all()
             assert (rm[cbf, ~live_m, 15] < -1e37).all()
-        parts = (wf.astype(np.uint32) << 16).view(np.float32)
-        total = parts[:, :, :, 0] + parts[:, :, :, 1] + parts[:, :, :, 2]      # [cbf][rb][kb][lane][8]
-        back = np.zeros_like(rm)
-        for rb in range(4):
-            for kb in range(2):
-                for lane in range(64):
-                    k0 = 16 * kb + 8 * (lane >> 5)
-                    back[:, 32 * rb + (lane & 31), k0:k0 + 8] = total[:, rb, kb, lane, :]
-        assert np.array_equal(back, rm), name
+            s = float(scale[cbf])
+            assert s == 2.0 ** round(np.log2(s)) and float(xconst[cbf]) == 2.0 ** round(np.log2(xconst[cbf]))
+            back = (W[cbf, 0].astype(np.float64) + W[cbf, 1].astype(np.float64)) * s
+            back[:, 15] *= float(xconst[cbf])
+            live = rm[cbf, live_m].astype(np.float64)
+            got = back[live_m]
+            # the constant: exactly what the record says (its parts were chosen for that)
+            assert np.array_equal(got[:, 15].astype(np.float32), rm[cbf, live_m, 15])
+            ab = np.r_[0:13, 16:29]
+            resid = np.abs(got[:, ab] - live[:, ab])
+            assert (resid <= np.maximum(np.abs(live[:, ab]) * 2.0 ** -22 * 1.001, 2.0 ** -25 * s)).all()
+            # inert rows: nothing but -65504 in the two spare slots, against X = 32768
+            assert (W[cbf, 0, ~live_m][:, [13, 14]] == np.float16(-65504)).all()
+            assert (np.delete(W[cbf, 0, ~live_m], [13, 14], axis=1) == 0).all()
+            assert (W[cbf, 1, ~live_m] == 0).all() and (W[cbf, :, live_m][:, :, [13, 14]] == 0).all()
+
+
+@pytest.mark.parametrize("name", ["en-us", "fr-fr"])
+def test_mfma_scan_bound_without_the_adder(oracle_mod, name):
+    """Everything of the matrix-core scan's bound that does not depend on the matrix core's
+    internal adder, replayed exactly: the operands the kernel builds (two binary16 parts of W from
+    the model's own tables, two of X cut as mfma_build_x cuts them), the three part products it
+    keeps, summed in float64.  Take away the most the six chained MFMAs may lose under the
+    assumed eps (2.01 eps M, ssw_model.c) and the widened key must still be >= the reference's
+    fp32 value -- for inputs near the means, noise, far-out points up to the +-255 the kernel
+    accepts, midpoints and the cancelling points x = 2 mean.  What is left to the device test
+    (tests/test_gpu_mfma_bound.py) is eps itself."""
+    m = ssw.Model(os.path.join(MODEL_ROOT, name), config={"device": -2})
+    o = oracle_mod.Model(os.path.join(MODEL_ROOT, name))
+    n_cbf, nd = m.n_cb * m.n_feat, m.n_density
+    rec = m.table("rec").reshape(n_cbf, nd, 32)
+    exm = m.table("scan_exact_mfma").reshape(n_cbf, 132)
+    W, d0, scale, xconst = mfma_operands(m)
+    mean4 = o.mean4()
+    rng = np.random.default_rng(20261003)
+    worst_use, worst_margin, n_pairs = 0.0, np.inf, 0
+    for cbf in range(n_cbf):
+        f = cbf % m.n_feat
+        x = input_families(mean4, f, 48, rng)
+        mu = rec[cbf, :, 0:13]
+        R = (rec[cbf, :, 16:29] * mu * mu).sum(axis=1)
+        worst_d = np.argsort(R)[-6:]
+        x = np.concatenate([x, 2 * mu[worst_d], np.nextafter(2 * mu[worst_d], np.float32(np.inf)),
+                            mu[worst_d], -2 * mu[worst_d],
+                            (rng.standard_normal((32, 13)) * 1e-4).astype(np.float32)]).astype(np.float32)
+        x = x[np.abs(x).max(axis=1) <= 255.0]          # beyond: the kernel does not trust the scan
+        X, p1, p2 = mfma_x_parts(x, float(xconst[cbf]))
+        W1, W2 = W[cbf, 0].astype(np.float64), W[cbf, 1].astype(np.float64)
+        X1, X2 = p1.astype(np.float64), p2.astype(np.float64)
+        kept = X1 @ (W1 + W2).T + X2 @ W1.T                      # (1,1) + (2,1) + (1,2), exact
+        M = np.abs(X1) @ np.abs(W1).T * (1 + 2.0 ** -9)          # sum of |products| the MFMAs see
+        live = np.ones(nd, bool)
+        live[exm[cbf, 1:1 + exm[cbf, 0]]] = False
+        assert (kept[:, ~live] < -4.0e9).all()                   # inert rows stay out of the way
+        s = float(scale[cbf])
+        low = ((kept - 2.01 * MFMA_EPS * M) * s)[:, live]        # the least the device may return
+        mean, var, det = rec[cbf, :, 0:13], rec[cbf, :, 16:29], rec[cbf, :, 15]
+        ref = np.broadcast_to(det, (len(x), nd)).astype(np.float32).copy()
+        for j in range(13):
+            diff = x[:, None, j] - mean[None, :, j]
+            ref = ref - (diff * diff) * var[None, :, j]
+        ref = ref[:, live]
+        ub = mfma_widen(low, d0[cbf]).astype(np.float64)
+        # float32 rounding of `low` itself (the MFMA result is a float): one more ulp, downwards
+        ub_min = ub - np.abs(ub) * 2.0 ** -23
+        assert (ub_min >= ref).all(), (name, cbf, float((ub_min - ref).min()))
+        worst_margin = min(worst_margin, float((ub_min - ref).min()))
+        room = MFMA_WIDEN * np.abs(low) + 1.0e-3
+        worst_use = max(worst_use, float(((ref - float(d0[cbf]) - low) / room).max()))
+        n_pairs += ref.size
+    assert worst_use < 1.0
+    print(f"{name}: {n_pairs} pairs, min margin {worst_margin:.4g}, share of the widening used {worst_use:.3f}")
