@@ -11,7 +11,7 @@ utterances -- the path partitions by utterance, there is no data-path collective
 reported value is the whole-job rate over the max-over-ranks time (weak scaling).
 
 Prints ONE JSON line on rank 0, including
-  `roofline`     dominant kernels, HIP-event timed on the launch stream;
+  `roofline`     dominant kernels, HIP-event timed on the launch stream over the timed region;
   `cpu_baseline` the CPU oracle timed on a bounded sample of the same workload on the host
                  cores of this box, one core and all cores (N = 1 only);
   `config5`      BASELINE.json configs[4] at every N: 2048 utterances x 1000 frames x 150 phones
@@ -42,7 +42,7 @@ UTT_FRAMES = 256
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, MI355X_MICROARCH.md
 N_SIMD = 1024                   # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9
-PMC_FILE = "r03_pmc.json"      # rocprofv3 --pmc passes of this step (tools/pmc_pass.py); only
+PMC_FILE = "r04_pmc.json"      # rocprofv3 --pmc passes of this step (tools/pmc_pass.py); only
                                # quoted when its kernel_src_sha equals this tree's
 
 
@@ -224,26 +224,34 @@ def spin_up(torch, step, seconds=0.5):
 
 
 def timed_steps(torch, dist, backend, step, warmup, steps):
+    """(host seconds over the K steps, max over ranks; this rank's device milliseconds over the
+    same K steps from two HIP events on the launch stream, recorded before the first launch and
+    after the last -- the step's kernels back to back with nothing of the host in between)"""
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)   # (the steps are launched on torch's current
+    ev1 = torch.cuda.Event(enable_timing=True)   # stream: ScoreStep.stream)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(steps):
         step()
+    ev1.record()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    region_ms = ev0.elapsed_time(ev1)
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed
+    return elapsed, region_ms
 
 
 def main():
@@ -316,7 +324,7 @@ def main():
     step = ScoreStep(torch, model, feats, utt_off)
     if not os.environ.get("SSW_BENCH_NO_SPIN"):   # (tools/pmc_pass.py: keep the trace short)
         spin_up(torch, step, float(os.environ.get("SSW_BENCH_SPIN", "0.5")))
-    elapsed = timed_steps(torch, dist, backend, step, args.warmup, args.steps)
+    elapsed, region_ms = timed_steps(torch, dist, backend, step, args.warmup, args.steps)
     k_ms = step.kernel_ms(max(1, min(args.steps, 50)))
     flagged, pairs = model.last_stats()
 
@@ -361,8 +369,13 @@ def main():
     total_frames = n_frames * world * args.steps
     fps = total_frames / elapsed
     # roofline of the hot path = the launches of one step (top-N pass, senone pass);
-    # algorithmic bytes = SURVEY 8(d)'s 72,345 B/frame x frames per launch set
-    path_ms = float(k_ms.sum())
+    # algorithmic bytes = SURVEY 8(d)'s 72,345 B/frame x frames per launch set.  Duration: the
+    # device time of the timed region's K steps (two HIP events on the launch stream around
+    # them) / K, i.e. the two kernels' launch durations plus the ~1 us between dependent
+    # launches.  (Rounds 1-3 summed per-kernel event pairs of a separate instrumented pass: an
+    # event between two launches costs ~2 us of its own, 5-10 % of a 35 us kernel -- those stay in
+    # `kernels` as the split, marked; profiles/r04_kernel_stats.csv has rocprofv3's durations.)
+    path_ms = region_ms / args.steps
     achieved = ab["path"] * n_frames / (path_ms * 1e-3) / 1e9
     sha = kernel_src_sha()
     traffic = valu_instr = None
@@ -420,7 +433,9 @@ def main():
                              "traffic: 61.5 of the 72 KB/frame are gathers from the 2 MB mixture-"
                              "weight table, which L2 serves; the path is VALU-issue bound "
                              "(DESIGN.md section 5): see valu_frac"},
-        "kernels": per_kernel,
+        "kernels": dict(per_kernel, note="per-kernel split from a separate pass with a HIP event "
+                        "between the two launches (each event adds ~2 us to what it brackets); "
+                        "their sum exceeds roofline.kernel_ms by that overhead"),
         # share of the SIMDs' vector issue slots the step uses at 4 cycles per wave64 instruction
         # (SQ_INSTS_VALU from the PMC file), at the nominal 2.4 GHz (the chip holds less under
         # this load, so the true share is higher)
@@ -441,8 +456,8 @@ def main():
             big = ScoreStep(torch, model, bf, boff)
             spin_up(torch, big, 0.3)   # the GPU idled while the host made the features (as for `value`)
             nst = 40 if big_utts == 64 else 20
-            e = timed_steps(torch, None, backend, big, 3, nst)
-            bk = big.kernel_ms(10)
+            e, e_dev = timed_steps(torch, None, backend, big, 3, nst)
+            bk = np.array([e_dev / nst])
             bab = algorithmic_bytes(model.n_sen, model.n_feat, model.topn, model.n_cb,
                                     model.n_density, model.veclen_total, big.n_frames)
             out[f"batch_{big.n_frames}"] = {
@@ -494,8 +509,8 @@ def real_features(ssw, model, torch, steps=50):
     off = (np.arange(N_UTTS + 1) * UTT_FRAMES).astype(np.int32)
     st = ScoreStep(torch, model, tiled, off)
     spin_up(torch, st, 0.3)
-    e = timed_steps(torch, None, "nccl", st, 5, steps)
-    k = st.kernel_ms(10)
+    e, e_dev = timed_steps(torch, None, "nccl", st, 5, steps)
+    k = np.array([e_dev / steps])
     flagged, pairs = model.last_stats()
     return {"workload": f"{len(cep)} frames of goforward.wav (cepstra -> ssw_feat_batch), tiled to "
                         f"{N_UTTS} x {UTT_FRAMES} frames",

@@ -25,7 +25,7 @@ import bench  # noqa: E402
 SETS = [["FETCH_SIZE"], ["WRITE_SIZE"],
         ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES",
          "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"],
-        ["SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_LDS_BANK_CONFLICT",
+        ["SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_LDS_BANK_CONFLICT",
          "SQ_LDS_IDX_ACTIVE", "SQ_BUSY_CYCLES"],
         ["GRBM_GUI_ACTIVE"]]
 
