@@ -176,7 +176,9 @@ int ssw_score_batch_stats(ssw_model_t *m, int64_t stats[2]);
 /* Per-kernel timing with HIP events recorded on the launch stream (for bench.py's roofline
  * line).  When enabled every ssw_score_batch call brackets each kernel with events;
  * ssw_get_kernel_timing synchronises and returns the last call's milliseconds:
- * ms[0] = top-N (density) kernel(s), ms[1] = senone kernel.  Returns the number written. */
+ * ms[0] = top-N (density) kernel(s), ms[1] = senone kernel -- or, for a batch large enough to be
+ * scored in pieces (scan and senone launches alternating), ms[0] = the whole call, ms[1] ~ 0.
+ * An event between two launches costs ~2 us of its own.  Returns the number written. */
 int ssw_set_kernel_timing(ssw_model_t *m, int enable);
 int ssw_get_kernel_timing(ssw_model_t *m, float *ms, int n);
 /* measurement aid: `reps` ssw_score_batch calls on the same batch back to back, then one
@@ -527,6 +529,9 @@ int ssw_gather_alignments(ssw_comm_t *c, const ssw_align_entry_t *local, int32_t
 /* device-memory helpers so a C caller needs no HIP headers */
 void *ssw_device_malloc(size_t nbytes);
 void ssw_device_free(void *d_ptr);
+/* free and total memory of the current device (hipMemGetInfo): a job sizes what it keeps
+ * resident by it (soundswallower_amd/jobs.py) */
+int ssw_device_mem_info(size_t *free_bytes, size_t *total_bytes);
 int ssw_memcpy_h2d(void *d_dst, const void *src, size_t nbytes);
 int ssw_memcpy_d2h(void *dst, const void *d_src, size_t nbytes);
 int ssw_device_synchronize(void);

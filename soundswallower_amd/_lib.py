@@ -197,6 +197,7 @@ def lib() -> C.CDLL:
     L.ssw_device_malloc.restype = vp
     L.ssw_device_malloc.argtypes = [sz]
     L.ssw_device_free.argtypes = [vp]
+    L.ssw_device_mem_info.argtypes = [vp, vp]
     L.ssw_memcpy_h2d.argtypes = [vp, vp, sz]
     L.ssw_memcpy_d2h.argtypes = [vp, vp, sz]
     _lib = L

@@ -12,6 +12,7 @@ of the job have committed checksums.
 """
 from __future__ import annotations
 
+import ctypes
 import time
 import zlib
 
@@ -21,7 +22,9 @@ from .parallel import gather_alignments, shard_utterances
 from .synth import synth_alignment_task, synth_features
 
 N_UTTS, N_FRAMES, N_PHONES, CHUNK_UTTS = 2048, 1000, 150, 256
-RESIDENT_BYTES = 64 << 30   # a shard whose senone scores take less stays resident as a whole
+RESIDENT_BYTES = 64 << 30   # a shard whose senone scores take less stays resident as a whole ...
+RESIDENT_SHARE = 0.5        # ... if that is at most this share of the device's FREE memory (the
+                            # scoring and alignment workspaces need about half as much again)
 
 
 class Config5Shard:
@@ -67,9 +70,19 @@ class Config5Shard:
             # next chunk (each three times slower for sharing the chip, and slowing the scoring)
             # cost more than one call at the end.  Beyond RESIDENT_BYTES: chunks, ping-pong.
             total = len(self.mine) * n_frames * model.n_sen * 2
-            self.resident = total <= RESIDENT_BYTES and chunk_utts >= CHUNK_UTTS
+            free_b = ctypes.c_size_t(0)
+            if model._L.ssw_device_mem_info(ctypes.byref(free_b), None) != 0:
+                free_b.value = 0            # (unknown: take the chunked path)
+            self.resident = (total <= RESIDENT_BYTES and total <= RESIDENT_SHARE * free_b.value
+                             and chunk_utts >= CHUNK_UTTS)
             nbytes = self.chunk_utts * n_frames * model.n_sen * 2
-            self.d_scr = model.device_malloc(total if self.resident else 2 * nbytes)
+            if self.resident:               # a smaller or shared GPU: fall back to the chunks
+                try:
+                    self.d_scr = model.device_malloc(total)
+                except Exception:           # noqa: BLE001 -- ssw_device_malloc failed
+                    self.resident = False
+            if not self.resident:
+                self.d_scr = model.device_malloc(2 * nbytes)
             self.d_scr2 = (self.d_scr, self.d_scr + (0 if self.resident else nbytes))
             self.s_score = model._L.ssw_stream_create()
             self.s_align = model._L.ssw_stream_create()

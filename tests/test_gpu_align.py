@@ -276,3 +276,63 @@ def test_edge_shapes_of_the_register_kernels(gpu_en, orc_en, monkeypatch, mode):
             n_ok += 1
             assert np.array_equal(st[phone_off[u] * 3:phone_off[u + 1] * 3], rst), (u, shapes[u])
     assert n_ok >= 8
+
+
+def test_fall_back_reruns_only_what_failed_from_the_callers_state(gpu_en, orc_en, monkeypatch):
+    """when an utterance outgrows a level (-(1 << 30)) only that utterance is run
+    again one level down, from the state entries the CALLER passed in (state_io is in / out),
+    not from whatever the failed level copied back.  A batch through the sliding-window kernel
+    with a window of two blocks: long utterances with narrow phone windows (stay), long ones
+    without (overflow, fall back), short ones, one without a path (too few frames) -- every one
+    starts from its own non-trivial entries (start / duration as alignment_populate would leave
+    them, a marker in the scores) and must come back as the oracle's state_align_search leaves
+    them: the aligned ones rewritten, the failing one's entries untouched."""
+    monkeypatch.setenv("SSW_ALIGN_KERNEL", "win")
+    monkeypatch.setenv("SSW_ALIGN_WIN_WAVES", "2")
+    shapes = [(300, 950), (300, 950), (5, 3), (192, 600), (40, 130), (192, 600), (8, 2)]
+    windowed = [True, False, False, False, False, True, False]
+    n_ph = [a for a, _ in shapes]
+    n_fr = [b for _, b in shapes]
+    frame_off = np.concatenate([[0], np.cumsum(n_fr)]).astype(np.int32)
+    phone_off = np.concatenate([[0], np.cumsum(n_ph)]).astype(np.int32)
+    scr = _random_senscr(int(frame_off[-1]), orc_en.n_sen, 1618)
+    rng = np.random.default_rng(3)
+    senid, tmat, sf, ef, init = [], [], [], [], []
+    for u, (p, f) in enumerate(shapes):
+        s_, t_, _ = synth_alignment_task(orc_en.sseq, orc_en.phone_ssid, orc_en.phone_tmat,
+                                         orc_en.n_ciphone, p, 1200 + u)
+        senid.append(s_)
+        tmat.append(t_)
+        a = np.zeros(p, np.int32)
+        b = np.full(p, 2**31 - 1, np.int32)
+        if windowed[u]:
+            mid = (np.arange(p) * f) // p
+            a = np.maximum(mid - 5, 0).astype(np.int32)
+            b = np.minimum(mid + f // p + 7, f).astype(np.int32)
+        sf.append(a)
+        ef.append(b)
+        init.append(np.stack([rng.integers(0, max(f, 1), 3 * p), rng.integers(1, 9, 3 * p),
+                              rng.integers(-999, -1, 3 * p)], 1).astype(np.int32))
+    senid, tmat = np.concatenate(senid), np.concatenate(tmat)
+    sf, ef, init = np.concatenate(sf), np.concatenate(ef), np.concatenate(init)
+    d = gpu_en.to_device(scr)
+    try:
+        st, status = gpu_en.align_batch(d, frame_off, phone_off, senid, tmat, sf=sf, ef=ef,
+                                        state_init=init)
+    finally:
+        gpu_en.device_free(d)
+    n_ok = n_bad = 0
+    for u in range(len(shapes)):
+        sl = slice(phone_off[u], phone_off[u + 1])
+        s3 = slice(phone_off[u] * 3, phone_off[u + 1] * 3)
+        rv, rst, _ = orc_en.state_align(scr[frame_off[u]:frame_off[u + 1]], senid[sl], tmat[sl],
+                                        sf=sf[sl], ef=ef[sl], state_init=init[s3])
+        assert (status[u] == 0) == (rv == 0), (u, shapes[u], status[u], rv)
+        assert status[u] != -(1 << 30)
+        if rv == 0:
+            n_ok += 1
+            assert np.array_equal(st[s3], rst), (u, shapes[u])
+        else:
+            n_bad += 1
+            assert np.array_equal(st[s3], init[s3]), (u, shapes[u])   # untouched
+    assert n_ok >= 5 and n_bad >= 1

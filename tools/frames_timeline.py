@@ -14,7 +14,19 @@ feats = np.concatenate([synth.synth_features(raw, 256, 12345 + u) for u in range
 off = np.arange(17, dtype=np.int32) * 256
 for i in range(5):
     out = m.score_batch_host(feats, off) if hasattr(m, "score_batch_host") else m.score_batch(feats, off)
-tl = np.fromfile("/tmp/tl.bin", dtype=np.uint64).reshape(-1, 6)
+raw_tl = np.fromfile("/tmp/tl.bin", dtype=np.uint64)
+tl2 = raw_tl[16384 * 6:].reshape(-1, 8) if len(raw_tl) > 16384 * 6 else None
+tl = raw_tl[:16384 * 6].reshape(-1, 6)
+if tl2 is not None:     # stamps inside the exact in-wave pass: entry, first pair's densities,
+    m2 = tl2[:, 0] != 0     # first pair's exact step, end; [4] = pairs redone
+    e = tl2[m2].astype(np.int64)
+    if len(e):
+        print("exact pass, %d waves: densities of the first pair p50 %d, its exact step p50 %d, "
+              "whole pass per pair p50 %d (pairs per wave mean %.2f)"
+              % (len(e), np.median(e[:, 1] - e[:, 0]), np.median(e[:, 2] - e[:, 1]),
+                 np.median((e[:, 3] - e[:, 0]) / np.maximum(e[:, 4], 1)), e[:, 4].mean()))
+        if len(sys.argv) > 1:
+            np.save(sys.argv[1] + ".exact.npy", e)
 tl = tl[tl[:, 0] != 0]
 if len(sys.argv) > 1:
     np.save(sys.argv[1], tl)
