@@ -93,11 +93,13 @@ int ssw_model_info(const ssw_model_t *m, ssw_model_info_t *out);
  * tables (no reference counterpart; exposed so the scan's error bound can be replayed on
  * the CPU): REC float32 [cb*feat][density][32] = mean[0..15) | det[15] | scale[16..31);
  * SCAN_REC the same shape holding the quadratic form a[0..15) | c[15] | b[16..31);
- * SCAN_D0 float32 [cb*feat][32], element 0 = the codebook's reference det;
+ * SCAN_D0 float32 [cb*feat][32], element 0 = the codebook's reference det (and, for the
+ * matrix-core scan, 1 = 2^s, 2 = 2^-s, 3 = 2^ec: its operands' scales, csrc/ssw_model.c);
  * SCAN_EXACT uint32 [cb*feat][132] = count, then the densities scored in the exact form;
  * SCAN_REC_MFMA / SCAN_EXACT_MFMA the same two for the matrix-core scan (its own error
- * constant), SCAN_WFRAG uint16 (bf16) [cb*feat][4][2][3][64][8]: those records cut into three
- * bf16 parts in MFMA A-fragment order. */
+ * constant; its c is what the two parts below add up to, unscaled), SCAN_WFRAG uint16
+ * (binary16) [cb*feat][4][2][2][64][8]: those records, scaled by 2^-s (c by 2^-(s + ec)), cut
+ * into two binary16 parts in MFMA A-fragment order. */
 enum ssw_table {
     SSW_TAB_MEAN = 0, SSW_TAB_VAR, SSW_TAB_DET, SSW_TAB_PTM_MIXW, SSW_TAB_MS_PDF, SSW_TAB_TP,
     SSW_TAB_SSEQ, SSW_TAB_SEN2CB, SSW_TAB_LOGADD8, SSW_TAB_PHONE_SSID, SSW_TAB_PHONE_TMAT,
@@ -163,6 +165,13 @@ int ssw_score_batch_host(ssw_model_t *m, int scorer, const float *feats, int32_t
 /* Debug/parity view of the PTM top-N state after normalisation for every frame of the last
  * ssw_score_batch* call: cw uint8 / score int32 laid out [n_frames][n_cb][n_feat][topn]. */
 int ssw_score_batch_topn(ssw_model_t *m, int32_t n_frames, uint8_t *cw, int32_t *score);
+/* Debug/parity view of the matrix core itself: D = A B + C, one v_mfma_f32_32x32x16_f16 per tile
+ * (host pointers; A [n_tiles][32][16], B [n_tiles][16][32] binary16 bit patterns, C, D
+ * [n_tiles][32][32] float).  The scan's error bound assumes an accumulation error of at most
+ * 34 x 2^-24 of the sum of the |terms| for this instruction (csrc/ssw_model.c);
+ * tests/test_gpu_mfma_bound.py measures it with this call. */
+int ssw_debug_mfma_f16_tiles(ssw_model_t *m, const uint16_t *A, const uint16_t *B, const float *C,
+                             float *D, int32_t n_tiles);
 /* Debug/parity view of the matrix-core scan: the raw keys (upper bounds of the densities,
  * relative to the codebook's reference level SCAN_D0, before their widening) of codebook x
  * stream `cbf` for every frame of d_feats, computed exactly as the scan computes them.

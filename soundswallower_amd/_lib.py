@@ -100,6 +100,7 @@ def lib() -> C.CDLL:
     L.ssw_score_batch_topn.argtypes = [vp, i32, vp, vp]
     L.ssw_score_batch_stats.argtypes = [vp, vp]
     L.ssw_debug_scan_keys.argtypes = [vp, vp, i32, i32, vp]
+    L.ssw_debug_mfma_f16_tiles.argtypes = [vp, vp, vp, vp, vp, i32]
     L.ssw_set_kernel_timing.argtypes = [vp, C.c_int]
     L.ssw_get_kernel_timing.argtypes = [vp, vp, C.c_int]
     L.ssw_ptm_mgau_init.restype = C.POINTER(SswMgau)

@@ -188,6 +188,19 @@ class Model:
         assert cw.size == n_frames * n_cbf * self.topn
         return cw, sc
 
+    def debug_mfma_f16_tiles(self, A, B, C):
+        """D = A B + C per tile on the matrix cores (one v_mfma_f32_32x32x16_f16 each):
+        A float16 [n][32][16], B float16 [n][16][32], C float32 [n][32][32]."""
+        A = np.ascontiguousarray(A, np.float16)
+        B = np.ascontiguousarray(B, np.float16)
+        C = np.ascontiguousarray(C, np.float32)
+        n = len(A)
+        assert A.shape == (n, 32, 16) and B.shape == (n, 16, 32) and C.shape == (n, 32, 32)
+        D = np.zeros_like(C)
+        _check(self._L.ssw_debug_mfma_f16_tiles(self._m, _ptr(A), _ptr(B), _ptr(C), _ptr(D), n),
+               "ssw_debug_mfma_f16_tiles")
+        return D
+
     def debug_scan_keys(self, feats, cbf):
         """Raw keys of the matrix-core scan for one codebook x stream: float32 [n_frames][128]."""
         feats = np.ascontiguousarray(feats, np.float32).reshape(-1, self.veclen_total)

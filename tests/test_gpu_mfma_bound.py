@@ -110,3 +110,50 @@ def test_mfma_keys_bound_the_reference_densities(gpu_en, gpu_fr, means_en, means
         slack.append(float(np.median(gap)))
     assert worst <= 0.0
     assert np.median(slack) < 64.0, "bounds this loose would flag a large share of the pairs"
+
+
+ASSUMED_EPS = 34.0 * 2.0 ** -24          # csrc/ssw_model.c: the one assumption the bound makes
+
+
+def test_accumulation_error_of_the_f16_mfma_is_within_the_assumed_eps(gpu_en):
+    """The scan's bound charges every v_mfma_f32_32x32x16_f16 with an error of at most eps = 34 u
+    (u = 2^-24) of the sum of the |terms| it adds (its 16 exact products and its C input): the
+    instruction's internal adder is not documented.  Measured here, on the device the tests run
+    on, against float64 over ~6 M results: random operands, dot products built to cancel against
+    C (the worst case for an adder that aligns to the largest term), operands spread over 2^+-10,
+    a C input a million times the products, terms of alternating sign and equal size, and one big
+    term beside fifteen small ones.  The worst ratio seen is printed; the margin to the
+    assumption is what the parity of the matrix-core scan rests on."""
+    rng = np.random.default_rng(20261003)
+    n = 1500
+    As, Bs, Cs = [], [], []
+    for mode in range(6):
+        A = (rng.random((n, 32, 16)) - 0.5) * 4.0
+        B = (rng.random((n, 16, 32)) - 0.5) * 4.0
+        C = (rng.random((n, 32, 32)) - 0.5)
+        if mode == 2:
+            A *= np.exp2(rng.integers(-10, 11, A.shape))
+            B *= np.exp2(rng.integers(-10, 11, B.shape))
+        if mode == 3:
+            C *= 1.0e6
+        if mode == 4:        # +t, -t, +t, ...: products of equal size and alternating sign
+            A = np.tile((rng.random((n, 32, 1)) + 0.5), (1, 1, 16)) * np.where(np.arange(16) % 2, -1.0, 1.0)
+            B = np.tile((rng.random((n, 1, 32)) + 0.5), (1, 16, 1))
+        if mode == 5:        # one term 2^12 times the others
+            A[:, :, 0] *= 4096.0
+        A16, B16 = A.astype(np.float16), B.astype(np.float16)
+        if mode in (1, 4):   # every dot product cancels against C to ~1e-3 of its size
+            dot = np.einsum("nik,nkj->nij", A16.astype(np.float64), B16.astype(np.float64))
+            C = -dot * (1.0 + 1.0e-3 * rng.random(dot.shape))
+        As.append(A16), Bs.append(B16), Cs.append(C.astype(np.float32))
+    A16, B16, C32 = np.concatenate(As), np.concatenate(Bs), np.concatenate(Cs)
+    D = gpu_en.debug_mfma_f16_tiles(A16, B16, C32).astype(np.float64)
+    a, b, c = A16.astype(np.float64), B16.astype(np.float64), C32.astype(np.float64)
+    exact = np.einsum("nik,nkj->nij", a, b) + c
+    terms = np.einsum("nik,nkj->nij", np.abs(a), np.abs(b)) + np.abs(c)
+    ratio = np.abs(D - exact) / terms
+    worst = [float(ratio[k * n:(k + 1) * n].max()) / 2.0 ** -24 for k in range(6)]
+    print("worst |D - exact| / sum |terms| in u, by input family:", [round(w, 2) for w in worst])
+    assert ratio.max() <= ASSUMED_EPS
+    assert max(worst) < 12.0, "the margin to the assumed 34 u has shrunk: look at csrc/ssw_model.c"
+    assert max(worst) > 0.4          # (a result that exact would mean the test measures nothing)
