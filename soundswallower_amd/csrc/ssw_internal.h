@@ -53,6 +53,9 @@ typedef struct ssw_host_model_s {
     float *recqm;
     uint32_t *exlistm;
     uint16_t *wfrag;
+    /* the exact records once more, packed for the matrix-core scan's LDS copy:
+     * rec28 [cb*feat][density][28] = mean 0..12 | det 13 | scale 14..26 | 0 */
+    float *rec28;
     int32_t n_exact_form_m;
     /* mdef */
     int32_t n_ciphone, n_phone, n_emit_state, n_ci_sen, n_sen, n_tmat, n_sseq, sil;

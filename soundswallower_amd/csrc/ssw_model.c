@@ -943,16 +943,30 @@ ssw_host_build_mfma_records(ssw_host_model_t *h)
     h->recqm = NULL;
     h->exlistm = NULL;
     h->wfrag = NULL;
+    h->rec28 = NULL;
     h->n_exact_form_m = 0;
     if (h->n_density != 128)
         return 0; /* the MFMA scan is built for 128 densities; other shapes use the FMA scan */
     h->recqm = (float *)calloc(nrec * SSW_REC_FLOATS, sizeof(float));
     h->exlistm = (uint32_t *)calloc((size_t)ncbf * SSW_EXLIST_STRIDE, sizeof(uint32_t));
     h->wfrag = (uint16_t *)calloc((size_t)ncbf * SSW_WFRAG_PER_CBF, sizeof(uint16_t));
+    h->rec28 = (float *)calloc(nrec * 28, sizeof(float));
+    if (h->rec28 != NULL) {
+        size_t i;
+        for (i = 0; i < nrec; ++i) {
+            const float *r = h->rec + i * SSW_REC_FLOATS;
+            float *q28 = h->rec28 + i * 28;
+            for (j = 0; j < 13; ++j) {
+                q28[j] = r[j];
+                q28[14 + j] = r[SSW_REC_VAR + j];
+            }
+            q28[13] = r[SSW_REC_DET];
+        }
+    }
     qd = (double *)calloc((size_t)h->n_density * SSW_REC_FLOATS, sizeof(double));
     geo = (double *)calloc((size_t)h->n_density * 4, sizeof(double));
     inert = (unsigned char *)calloc((size_t)h->n_density, 1);
-    if (!h->recqm || !h->exlistm || !h->wfrag || !qd || !geo || !inert) {
+    if (!h->recqm || !h->exlistm || !h->wfrag || !h->rec28 || !qd || !geo || !inert) {
         free(qd);
         free(geo);
         free(inert);
@@ -1325,6 +1339,7 @@ ssw_host_model_free(ssw_host_model_t *h)
     free(h->recqm);
     free(h->exlistm);
     free(h->wfrag);
+    free(h->rec28);
     free(h->sseq);
     free(h->sen2cb);
     free(h->phone_ssid);

@@ -481,3 +481,27 @@ def test_features_beyond_the_binary16_range_take_the_exact_pass(gpu_en, orc_en, 
     assert np.array_equal(got, ref)
     # a frame beyond the limit in one stream sends that stream's 42 pairs through the exact pass
     assert beyond.sum() * 42 <= flagged <= beyond.sum() * 126 + pairs // 200
+
+
+def test_one_and_two_step_scan_waves_agree_on_piece_sized_launches(gpu_en, orc_en, means_en, monkeypatch):
+    """From 12,288 frames per launch a scan wave takes two 64-frame steps instead of one
+    (csrc/ssw_host_score.inc).  32,768 frames (two pieces of 16,384): one step per wave, two steps,
+    the default, four workgroups per CU instead of five (SSW_MFMA_LDS_PAD) -- identical rows,
+    and a sample of utterances against the oracle.  (Round 4 shipped the two-step instance for a
+    few commits with its utterance-start bits read through an inline-asm scalar load whose wait
+    sat in a second statement; the compiler spilled the register pair in between.  Two rows of
+    this batch differed, a different set with other occupancy.)"""
+    feats = np.concatenate([synth_features(means_en, 256, 9000 + u) for u in range(128)])
+    off = (np.arange(129) * 256).astype(np.int32)
+    monkeypatch.setenv("SSW_MFMA_STEPS", "1")
+    one = gpu_en.score_batch(feats, off)
+    monkeypatch.setenv("SSW_MFMA_STEPS", "2")
+    assert np.array_equal(gpu_en.score_batch(feats, off), one)
+    monkeypatch.setenv("SSW_MFMA_LDS_PAD", "2048")
+    assert np.array_equal(gpu_en.score_batch(feats, off), one)
+    monkeypatch.delenv("SSW_MFMA_STEPS")
+    assert np.array_equal(gpu_en.score_batch(feats, off), one)
+    monkeypatch.delenv("SSW_MFMA_LDS_PAD")
+    assert np.array_equal(gpu_en.score_batch(feats, off), one)
+    for u in (0, 16, 17, 63, 64, 127):
+        assert np.array_equal(one[off[u]:off[u + 1]], orc_en.ptm_score_utt(feats[off[u]:off[u + 1]])), u
