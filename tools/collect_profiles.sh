@@ -1,24 +1,24 @@
 #!/bin/bash
 # Everything the round's profiles/ files come from, in one call ON the GPU box:
-#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r03'
+#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r04'
 # Writes gpurun_out/<tag>/; copy what is to be judged into profiles/<tag>_* afterwards
 # (tools/collect_profiles.sh does not touch profiles/).  rocprofv3 gets `python3 <script>` directly
 # after `--` (no shell, no env in between) and --pmc passes are never combined with other traces.
-tag=${1:-r03}
+tag=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
 export TMPDIR=/tmp
 cd $R
 if [ "$2" != "notests" ]; then
-  python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1
+  timeout 600 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1
   grep -E "passed|failed" $O/pytest.log | tail -2
 fi
-python bench.py > $O/bench_line.json 2> $O/bench.err
+timeout 600 python bench.py > $O/bench_line.json 2> $O/bench.err
 cd /tmp
 prof() {  # name, then the program
   local name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o $name -- "$@" > $O/${name}_under_rocprof.json 2> $O/${name}_rocprof.err
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o $name -- "$@" > $O/${name}_under_rocprof.json 2> $O/${name}_rocprof.err
   find $O/prof_$name -name "*kernel_stats.csv" -exec cp {} $O/${name}_kernel_stats.csv \;
   find $O/prof_$name -name "*kernel_trace.csv" -delete
 }
@@ -29,11 +29,11 @@ prof config3_align python3 $R/tools/bench_align.py
 prof first_pass python3 $R/tools/bench_first_pass.py --reps 5
 prof page python3 $R/tools/bench_page.py
 cd $R
-python3 tools/pmc_pass.py $tag > $O/pmc.log 2>&1
+timeout 900 python3 tools/pmc_pass.py $tag > $O/pmc.log 2>&1
 tail -2 $O/pmc.log
-python tools/bench_page.py > $O/page.json 2>/dev/null
-python tools/bench_frame_sync.py > $O/frame_sync.json 2>/dev/null
-python tools/bench_first_pass.py --reps 5 > $O/first_pass.json 2>/dev/null
-python tools/bench_ms.py > $O/config4_ms.json 2>/dev/null
-python tools/bench_align.py > $O/config3_align.json 2>/dev/null
+timeout 300 python tools/bench_page.py > $O/page.json 2>/dev/null
+timeout 300 python tools/bench_frame_sync.py > $O/frame_sync.json 2>/dev/null
+timeout 300 python tools/bench_first_pass.py --reps 5 > $O/first_pass.json 2>/dev/null
+timeout 300 python tools/bench_ms.py > $O/config4_ms.json 2>/dev/null
+timeout 300 python tools/bench_align.py > $O/config3_align.json 2>/dev/null
 ls $O

@@ -5,7 +5,7 @@ One `rocprofv3 --pmc <counters of one block> --kernel-trace` pass per counter se
 combined with another trace domain), over `python3 bench.py --steps 5 --warmup 2 --no-align
 --no-extra --no-cpu-baseline` with the spin-up loop off; per-kernel averages go to
 gpurun_out/<tag>_pmc.json together with the hash of the kernel sources they were taken on
-(bench.py quotes `roofline.traffic` from profiles/r02_pmc.json only when that hash is the
+(bench.py quotes `roofline.traffic` from profiles/<tag>_pmc.json only when that hash is the
 tree's).  HBM bytes per MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are KiB;
 on gfx950 FETCH_SIZE reads half the bytes of a wide (16 B per lane) coalesced stream, other
 widths are uncalibrated -- both the raw figure and the doubled one are kept."""
@@ -31,7 +31,7 @@ SETS = [["FETCH_SIZE"], ["WRITE_SIZE"],
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     os.chdir(ROOT)
     env = dict(os.environ, TMPDIR="/tmp", SSW_BENCH_NO_SPIN="1")
     per = collections.defaultdict(dict)
