@@ -1,8 +1,8 @@
 #!/bin/bash
 # Randomised GPU-vs-oracle soaks on the current build (ON the GPU box):
-#   gpurun --timeout 3000 -- 'bash tools/run_soaks.sh r03 240'
+#   gpurun --timeout 3000 -- 'bash tools/run_soaks.sh r04 240'
 # Writes gpurun_out/<tag>_parity_soak_*.json (copy into profiles/ to keep them).
-tag=${1:-r03}
+tag=${1:-r04}
 secs=${2:-240}
 O=$GRAFT_REPO_ROOT/gpurun_out
 cd $GRAFT_REPO_ROOT
