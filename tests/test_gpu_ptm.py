@@ -505,3 +505,30 @@ def test_one_and_two_step_scan_waves_agree_on_piece_sized_launches(gpu_en, orc_e
     assert np.array_equal(gpu_en.score_batch(feats, off), one)
     for u in (0, 16, 17, 63, 64, 127):
         assert np.array_equal(one[off[u]:off[u + 1]], orc_en.ptm_score_utt(feats[off[u]:off[u + 1]])), u
+
+
+def test_chain_over_utterances_with_frame_downsampling(oracle_mod, means_en):
+    """ds = 2 (codebooks re-scanned every other frame, src/ptm_mgau.c:241) takes the sequential
+    kernel; with SSW_SCORE_CARRY_UTTS one wave walks all utterances of a codebook x stream: the
+    frame numbers -- and with them the ds phase and the history ring -- restart at every
+    utterance.  Odd, one-frame and empty utterances against the oracle's chain."""
+    import soundswallower_amd as ssw
+    mdir = ssw.model_dir("en-us")
+    g = ssw.Model(mdir, config={"ds": 2})
+    o = oracle_mod.Model(mdir, config={"ds": 2})
+    feats, off = _ring_features(o, means_en, 500)
+    want = o.ptm_score_chain(feats, off)
+    got, _ = g.score_batch_carry(feats, off, carry_utts=True)
+    assert np.array_equal(got, want)
+    plain = g.score_batch(feats, off)
+    ref = np.concatenate([o.ptm_score_utt(feats[off[u]:off[u + 1]]) for u in range(len(off) - 1)
+                          if off[u + 1] > off[u]])
+    assert np.array_equal(plain, ref)
+    g.close()
+
+
+def test_device_mem_info(gpu_en):
+    import ctypes
+    free_b, total_b = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert gpu_en._L.ssw_device_mem_info(ctypes.byref(free_b), ctypes.byref(total_b)) == 0
+    assert 0 < free_b.value <= total_b.value and total_b.value > (100 << 30)   # an MI355X: 288 GB
