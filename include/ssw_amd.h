@@ -26,6 +26,12 @@
  * 0) where the reference's `(int32)` casts follow the host CPU's (x86: 0x80000000) -- the
  * scores of such a frame are defined, but not the reference's.  Hosts that cannot rule
  * non-finite cepstra out should screen them before ssw_feat_batch / ssw_score_batch.
+ * Range: any finite feature gives the reference's scores, but the fast path of the scoring
+ * kernels (the matrix-core scan, binary16 operands) only trusts frames whose features lie
+ * within +-255 -- cepstral features of the shipped front end are a tenth of that; a frame
+ * beyond takes the exact in-wave pass, ~13 x the work.  Data in another scale altogether
+ * (integer-scaled cepstra) is scored fastest with SSW_SCAN=fma, the vector-unit scan, which
+ * has fp32's range.
  */
 #ifndef SSW_AMD_H
 #define SSW_AMD_H
