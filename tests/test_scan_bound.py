@@ -120,15 +120,16 @@ def test_widening_is_monotone():
         assert np.all(np.diff(w) >= 0)
 
 
-def write_hostile_gaussians(tmp_path, n_cb=2, n_feat=3, nd=128, vl=13, seed=11):
+def write_hostile_gaussians(tmp_path, n_cb=2, n_feat=3, nd=128, vl=13, seed=11,
+                            scales=(1.0, 30.0, 300.0), var_lo=1e-5):
     """means / variances files (s3 gauden parameter layout, src/ms_gauden.c:105-216) with
     means up to a few hundred and variances from below the floor to 10."""
     from tests.test_cabi_host import _write_s3
     import struct
     rng = np.random.default_rng(seed)
-    scale = rng.choice([1.0, 30.0, 300.0], (n_cb, n_feat, nd, 1))
+    scale = rng.choice(list(scales), (n_cb, n_feat, nd, 1))
     mean = (rng.standard_normal((n_cb, n_feat, nd, vl)) * scale).astype("<f4")
-    var = np.exp(rng.uniform(np.log(1e-5), np.log(10.0), (n_cb, n_feat, nd, vl))).astype("<f4")
+    var = np.exp(rng.uniform(np.log(var_lo), np.log(10.0), (n_cb, n_feat, nd, vl))).astype("<f4")
     paths = {}
     for nm, arr in (("means", mean), ("variances", var)):
         payload = struct.pack("<3i", n_cb, n_feat, nd) + struct.pack(f"<{n_feat}i", *([vl] * n_feat))
@@ -248,28 +249,17 @@ def test_mfma_scan_records_are_consistent_with_the_fma_ones():
             assert (W[cbf, 1, ~live_m] == 0).all() and (W[cbf, :, live_m][:, :, [13, 14]] == 0).all()
 
 
-@pytest.mark.parametrize("name", ["en-us", "fr-fr"])
-def test_mfma_scan_bound_without_the_adder(oracle_mod, name):
-    """Everything of the matrix-core scan's bound that does not depend on the matrix core's
-    internal adder, replayed exactly: the operands the kernel builds (two binary16 parts of W from
-    the model's own tables, two of X cut as mfma_build_x cuts them), the three part products it
-    keeps, summed in float64.  Take away the most the six chained MFMAs may lose under the
-    assumed eps (2.01 eps M, ssw_model.c) and the widened key must still be >= the reference's
-    fp32 value -- for inputs near the means, noise, far-out points up to the +-255 the kernel
-    accepts, midpoints and the cancelling points x = 2 mean.  What is left to the device test
-    (tests/test_gpu_mfma_bound.py) is eps itself."""
-    m = ssw.Model(os.path.join(MODEL_ROOT, name), config={"device": -2})
-    o = oracle_mod.Model(os.path.join(MODEL_ROOT, name))
+def _mfma_bound_without_the_adder(m, mean4, rng, tag, n_in=48, min_live=1):
+    """the body of the two tests below: returns (pairs checked, min margin, largest share of
+    the widening used)"""
     n_cbf, nd = m.n_cb * m.n_feat, m.n_density
     rec = m.table("rec").reshape(n_cbf, nd, 32)
     exm = m.table("scan_exact_mfma").reshape(n_cbf, 132)
     W, d0, scale, xconst = mfma_operands(m)
-    mean4 = o.mean4()
-    rng = np.random.default_rng(20261003)
     worst_use, worst_margin, n_pairs = 0.0, np.inf, 0
     for cbf in range(n_cbf):
         f = cbf % m.n_feat
-        x = input_families(mean4, f, 48, rng)
+        x = input_families(mean4, f, n_in, rng)
         mu = rec[cbf, :, 0:13]
         R = (rec[cbf, :, 16:29] * mu * mu).sum(axis=1)
         worst_d = np.argsort(R)[-6:]
@@ -285,6 +275,8 @@ def test_mfma_scan_bound_without_the_adder(oracle_mod, name):
         live = np.ones(nd, bool)
         live[exm[cbf, 1:1 + exm[cbf, 0]]] = False
         assert (kept[:, ~live] < -4.0e9).all()                   # inert rows stay out of the way
+        if live.sum() < min_live:
+            continue
         s = float(scale[cbf])
         low = ((kept - 2.01 * MFMA_EPS * M) * s)[:, live]        # the least the device may return
         mean, var, det = rec[cbf, :, 0:13], rec[cbf, :, 16:29], rec[cbf, :, 15]
@@ -296,10 +288,46 @@ def test_mfma_scan_bound_without_the_adder(oracle_mod, name):
         ub = mfma_widen(low, d0[cbf]).astype(np.float64)
         # float32 rounding of `low` itself (the MFMA result is a float): one more ulp, downwards
         ub_min = ub - np.abs(ub) * 2.0 ** -23
-        assert (ub_min >= ref).all(), (name, cbf, float((ub_min - ref).min()))
-        worst_margin = min(worst_margin, float((ub_min - ref).min()))
+        ok = np.isfinite(ref)
+        assert (ub_min[ok] >= ref[ok]).all(), (tag, cbf, float((ub_min - ref)[ok].min()))
+        worst_margin = min(worst_margin, float((ub_min - ref)[ok].min()))
         room = MFMA_WIDEN * np.abs(low) + 1.0e-3
-        worst_use = max(worst_use, float(((ref - float(d0[cbf]) - low) / room).max()))
-        n_pairs += ref.size
-    assert worst_use < 1.0
+        worst_use = max(worst_use, float(((ref - float(d0[cbf]) - low) / room)[ok].max()))
+        n_pairs += int(ok.sum())
+    return n_pairs, worst_margin, worst_use
+
+
+@pytest.mark.parametrize("name", ["en-us", "fr-fr"])
+def test_mfma_scan_bound_without_the_adder(oracle_mod, name):
+    """Everything of the matrix-core scan's bound that does not depend on the matrix core's
+    internal adder, replayed exactly: the operands the kernel builds (two binary16 parts of W from
+    the model's own tables, two of X cut as mfma_build_x cuts them), the three part products it
+    keeps, summed in float64.  Take away the most the six chained MFMAs may lose under the
+    assumed eps (2.01 eps M, ssw_model.c) and the widened key must still be >= the reference's
+    fp32 value -- for inputs near the means, noise, far-out points up to the +-255 the kernel
+    accepts, midpoints and the cancelling points x = 2 mean.  What is left to the device test
+    (tests/test_gpu_mfma_bound.py) is eps itself."""
+    m = ssw.Model(os.path.join(MODEL_ROOT, name), config={"device": -2})
+    o = oracle_mod.Model(os.path.join(MODEL_ROOT, name))
+    rng = np.random.default_rng(20261003)
+    n_pairs, worst_margin, worst_use = _mfma_bound_without_the_adder(m, o.mean4(), rng, name)
+    assert n_pairs > 5_000_000 and worst_use < 1.0
     print(f"{name}: {n_pairs} pairs, min margin {worst_margin:.4g}, share of the widening used {worst_use:.3f}")
+
+
+def test_mfma_scan_bound_on_a_hostile_model(tmp_path):
+    """The same replay on records the shipped models do not contain: means up to a few hundred,
+    variances from below the floor to 10 (scales of W from 2^-8 to 2^20 and beyond, elements that
+    lose their second binary16 part, constants that need the 2^ec slot): what the host cannot
+    cover lands on the exact-form list, the rest satisfies the bound."""
+    paths = write_hostile_gaussians(tmp_path, n_cb=4, seed=23, scales=(0.3, 3.0, 20.0), var_lo=0.02)
+    m = ssw.Model(config={"device": -2}, **paths)
+    n_cbf = m.n_cb * m.n_feat
+    mean4 = m.table("rec").reshape(m.n_cb, m.n_feat, m.n_density, 32)[:, :, :, 0:13]
+    exm = m.table("scan_exact_mfma").reshape(n_cbf, 132)
+    assert 0 < exm[:, 0].sum() < n_cbf * m.n_density        # some densities in, some out
+    rng = np.random.default_rng(5)
+    n_pairs, worst_margin, worst_use = _mfma_bound_without_the_adder(m, mean4, rng, "hostile", n_in=96)
+    assert n_pairs > 20_000 and worst_use < 1.0
+    print(f"hostile: {n_pairs} pairs, {int(exm[:, 0].sum())} of {n_cbf * m.n_density} densities exact-form, "
+          f"min margin {worst_margin:.4g}, share of the widening used {worst_use:.3f}")
