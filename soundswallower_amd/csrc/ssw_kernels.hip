@@ -11,12 +11,13 @@
  * anonymous namespace, then the host side):
  *   ssw_dev_common.inc   truncation, density, wave reductions, LDS-only barrier
  *   ssw_k1a_chain.inc    ptm_topn_chain_kernel (exact frame-sequential top-N: eval_topn + eval_cb,
- *                        src/ptm_mgau.c:86-225) and ptm_topn_fixup_kernel (the exact pass behind
- *                        the speculative one)
- *   ssw_k1a_frames.inc   ptm_topn_frames_kernel (speculative history-free top-N with a proof
- *                        test per pair), ms_topn_fixup_kernel
+ *                        src/ptm_mgau.c:86-225) and topn_exact_step, the exact step the scans'
+ *                        in-wave pass shares
+ *   ssw_k1a_frames.inc   ptm_topn_frames_kernel (speculative history-free top-N on the vector
+ *                        unit with a proof test per pair; the exact in-wave pass and its helpers)
  *   ssw_k1a_mfma.inc     ptm_topn_mfma_kernel: the same scan with its multiply-adds on the matrix
- *                        cores (split-bf16 MFMA keys, exact re-evaluation and in-wave pass as above)
+ *                        cores (keys from two-part binary16 operands, exact re-evaluation and
+ *                        in-wave pass as above): what every batch takes
  *   ssw_k1b_senone.inc   ptm_senone_kernel (codebook_norm + senone_eval, src/ptm_mgau.c:264-403),
  *                        ptm_senone_frame_kernel (one frame, active sets), ms_senone_kernel
  *   ssw_k4_feat.inc      feat_1s_c_d_dd_kernel (batch CMN + 1s_c_d_dd, src/feat.c:271-326)
