@@ -157,3 +157,47 @@ def test_accumulation_error_of_the_f16_mfma_is_within_the_assumed_eps(gpu_en):
     assert ratio.max() <= ASSUMED_EPS
     assert max(worst) < 12.0, "the margin to the assumed 34 u has shrunk: look at csrc/ssw_model.c"
     assert max(worst) > 0.4          # (a result that exact would mean the test measures nothing)
+
+
+def test_accumulation_error_adversarial_alignment(gpu_en):
+    """The two adder models behind the assumed eps (csrc/ssw_model.c) are worst cases, not
+    measurements: (B) says the 17 terms are aligned to the largest exponent, cut to a 24-bit
+    grid, summed exactly and rounded once -- 16 x 2 u + 2 u = 34 u.  Random data sits far below
+    that (test above: 6 u).  Here the inputs are built to hit model B's worst case and to find
+    out what the hardware's grid really is: ONE big product and fifteen products of the same
+    sign just below a fraction 2^-j of the big one's ulp (j = 0 .. 5), and just above it; with
+    C = 0, with C the big term instead, and with all sixteen products small against a big C.  A
+    truncating aligner loses (nearly) every small term at j = 0: ~30 u.  Whatever the hardware
+    does, the error must stay within the assumed 34 u of the sum of the |terms|; the worst ratio
+    per family is printed."""
+    fams = []
+    for j in range(6):
+        for above in (False, True):
+            for where in ("product", "c"):
+                fams.append((j, above, where))
+    n = len(fams)
+    A = np.zeros((n, 32, 16), np.float64)
+    B = np.zeros((n, 16, 32), np.float64)
+    C = np.zeros((n, 32, 32), np.float64)
+    big = 4096.0                                   # ulp(big) in fp32 = 2^-11
+    for i, (j, above, where) in enumerate(fams):
+        frac = (1.0 + 2.0 ** -10) if above else (1.0 - 2.0 ** -11)      # binary16-representable
+        small = 2.0 ** (-11 - j) * frac           # the product wanted: ulp(big) 2^-j (1 -+ eps)
+        # small = a_k * b_k with a_k = 2^-5 frac, b_k = 2^(-6 - j)
+        A[i, :, :] = 2.0 ** -5 * frac
+        B[i, :, :] = 2.0 ** (-6 - j)
+        if where == "product":
+            A[i, :, 0] = 64.0
+            B[i, 0, :] = 64.0                      # the big product, 4096
+        else:
+            C[i] = big
+    A16, B16, C32 = A.astype(np.float16), B.astype(np.float16), C.astype(np.float32)
+    assert np.array_equal(A16.astype(np.float64), A) and np.array_equal(B16.astype(np.float64), B)
+    D = gpu_en.debug_mfma_f16_tiles(A16, B16, C32).astype(np.float64)
+    exact = np.einsum("nik,nkj->nij", A, B) + C
+    terms = np.einsum("nik,nkj->nij", np.abs(A), np.abs(B)) + np.abs(C)
+    ratio = (np.abs(D - exact) / terms).reshape(n, -1).max(axis=1) / 2.0 ** -24
+    for (j, above, where), r in zip(fams, ratio):
+        print("small terms %s 2^-%d ulp of the big %s: %.2f u" % ("above" if above else "below", j,
+                                                                 where, r))
+    assert ratio.max() <= 34.0, "the accumulation error passes the eps the scan's bound assumes"
