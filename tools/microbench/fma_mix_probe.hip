@@ -23,6 +23,8 @@ __global__ void probe(uint32_t *n_diff, uint32_t *first)
         float v = hf + cell * (float)k * (1.0f / 64.0f);
         for (int nudge = -1; nudge <= 1; ++nudge) {
             float vv = __uint_as_float(__float_as_uint(v) + nudge);
+            if (vv != vv)                       // (0 - 1 ulp as bits: a NaN; payloads may differ)
+                continue;
             const float2v pr = { vv, vv };
             const f16x2 cv = __builtin_convertvector(pr, f16x2);      // as the kernel converts
             const uint32_t packed = __builtin_bit_cast(uint32_t, cv);
