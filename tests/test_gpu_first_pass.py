@@ -546,6 +546,36 @@ def test_hbm_resident_kernel_equals_the_register_one(oracle_mod, gpu_en, gpu_fr,
             [(w, s, s + d - 1, sc) for (w, s, d, sc) in big[t]] == want
 
 
+def test_a_level_reruns_only_what_it_left_unfinished(oracle_mod, gpu_en, orc_en, monkeypatch):
+    """when a level of the long-text path gives up on SOME utterances of a batch, only
+    those are searched again one level down (FirstPassParams::only); the others keep what they
+    have.  One-word texts (a handful of word-final HMMs: within a history budget of 24 entries
+    per frame) beside eight-word texts (beyond it), interleaved, with the long-text kernels
+    forced on them: every segmentation equals the unforced call's, whichever level wrote it."""
+    F, olex = _olex(oracle_mod, orc_en, "en-us")
+    lex = _lex(gpu_en, "en-us")
+    vocab = [w for w in olex.order[:olex.filler_start] if "(" not in w]
+    u = lcg_uniform(23, 20 * 10)
+    texts, scores = [], []
+    for t in range(20):
+        n = 1 if t % 2 == 0 else 8
+        texts.append([vocab[int(x * len(vocab))] for x in u[t * 10 + 1:t * 10 + 1 + n]])
+        scores.append(synth_scores(F, orc_en, olex, texts[-1], 500 + t, orc_en.n_sen))
+    plain = _first_pass(gpu_en, lex, scores, texts)
+    assert sum(g is not None for g in plain) >= 16
+    _forced_big(monkeypatch)
+    for budget in ("24", "6", "1"):
+        monkeypatch.setenv("SSW_FP_HIST_BAND", budget)
+        assert _first_pass(gpu_en, lex, scores, texts) == plain, budget
+        monkeypatch.setenv("SSW_FP_WIN", "0")          # ... and from the HBM-resident level down
+        assert _first_pass(gpu_en, lex, scores, texts) == plain, budget
+        monkeypatch.delenv("SSW_FP_WIN")
+    for t in (0, 1, 6, 7):
+        want = F.first_pass(orc_en, olex, texts[t], scores[t])
+        assert (want is None and plain[t] is None) or \
+            [(w, s, s + d - 1, sc) for (w, s, d, sc) in plain[t]] == want
+
+
 @pytest.mark.timeout(900)
 def test_a_page_of_2000_words(oracle_mod, gpu_en, orc_en):
     """a 2,000-word text (about 19 K phone-tree HMMs, 8 K word-final ones,
