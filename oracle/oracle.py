@@ -92,6 +92,7 @@ def lib() -> C.CDLL:
                                   vp, vp, vp]
     L.orc_fe_mfcc.argtypes = [vp, C.c_size_t, C.c_int, f64, f64, C.c_int, C.c_int, C.c_int, vp, C.c_int]
     L.orc_feat_1s_c_d_dd.argtypes = [vp, C.c_int, vp]
+    L.orc_feat_1s_c_d_dd_ex.argtypes = [vp, C.c_int, vp, C.c_int]
     L.orc_hmm_vit_eval.restype = i32
     L.orc_scan_replay.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]
     L.orc_scan_replay.restype = None
@@ -351,11 +352,11 @@ def fe_mfcc(pcm, nfilt=40, lowerf=133.33334, upperf=6855.4976, lifter=0, remove_
     return cep[:n].copy()
 
 
-def feat_1s_c_d_dd(cep):
-    """Batch CMN + 1s_c_d_dd dynamic features: [n][13] -> [n][39]."""
+def feat_1s_c_d_dd(cep, cmn=True):
+    """Batch CMN + 1s_c_d_dd dynamic features: [n][13] -> [n][39].  cmn=False: "-cmn none"."""
     cep = np.ascontiguousarray(cep, np.float32).copy()
     out = np.zeros((cep.shape[0], 39), np.float32)
-    lib().orc_feat_1s_c_d_dd(_ptr(cep), cep.shape[0], _ptr(out))
+    lib().orc_feat_1s_c_d_dd_ex(_ptr(cep), cep.shape[0], _ptr(out), 1 if cmn else 0)
     return out
 
 

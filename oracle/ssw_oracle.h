@@ -162,6 +162,7 @@ int orc_fe_mfcc(const int16_t *pcm, size_t n_samps, int nfilt, double lowerf, do
                 int lifter, int remove_noise_flag, int legacy_transform, float *cep,
                 int max_frames);
 int orc_feat_1s_c_d_dd(float *cep, int n, float *out);
+int orc_feat_1s_c_d_dd_ex(float *cep, int n, float *out, int cmn);
 
 #ifdef __cplusplus
 }

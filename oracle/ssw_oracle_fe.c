@@ -450,6 +450,14 @@ orc_fe_mfcc(const int16_t *pcm, size_t n_samps, int nfilt, double lowerf, double
 int
 orc_feat_1s_c_d_dd(float *cep, int n, float *out)
 {
+    return orc_feat_1s_c_d_dd_ex(cep, n, out, 1);
+}
+
+/* cmn = 0: "-cmn none", the configuration of the reference's own tests/test_feat.c:51-55, whose
+ * golden table tests/_test_feat.res the oracle is pinned to (tests/test_reference_pins.py) */
+int
+orc_feat_1s_c_d_dd_ex(float *cep, int n, float *out, int cmn)
+{
     const int C = 13, W = 3; /* window = FEAT_DCEP_WIN + 1 */
     float sum[13], mean[13];
     float **row;
@@ -458,7 +466,7 @@ orc_feat_1s_c_d_dd(float *cep, int n, float *out)
     if (n <= 0)
         return 0;
     memset(sum, 0, sizeof(sum));
-    for (f = 0; f < n; ++f) {
+    for (f = 0; f < n && cmn; ++f) {
         const float *c = cep + (size_t)f * C;
         if (c[0] < 0) /* "skip zero energy frames" */
             continue;
@@ -467,8 +475,8 @@ orc_feat_1s_c_d_dd(float *cep, int n, float *out)
         ++nframe;
     }
     for (i = 0; i < C; ++i)
-        mean[i] = sum[i] / nframe;
-    for (f = 0; f < n; ++f)
+        mean[i] = cmn ? sum[i] / nframe : 0.0f;
+    for (f = 0; f < n && cmn; ++f)
         for (i = 0; i < C; ++i)
             cep[(size_t)f * C + i] -= mean[i];
     /* pad W frames each side with copies of the first / last frame */
