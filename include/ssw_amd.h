@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SSW_ABI_VERSION 1
+#define SSW_ABI_VERSION 2 /* 2: ssw_model_info_t grew (scan_mode ..), round 5 */
 
 /* ------------------------------------------------------------------------------------ */
 /* Configuration: the scalar parameters the path reads from config_t                     */
@@ -87,8 +87,20 @@ typedef struct ssw_model_info_s {
     int32_t n_sen, n_ci_sen, n_ciphone, n_phone, n_emit_state, n_tmat, n_sseq, sil;
     int32_t n_floored, topn, has_ptm, has_ms, device;
     int32_t veclen[8];
+    /* ABI 2.  The speculative top-N scan runs on the matrix cores only on a device that has
+     * passed the load-time self-test of the one hardware property its error bound assumes (the
+     * accumulation error of v_mfma_f32_32x32x16_f16, csrc/ssw_model.c): ssw_model_load measures
+     * it with adversarial and random cancelling tiles against fp64 / closed-form sums, and on a
+     * failure (or a HIP error) every batch takes the vector-unit scan, whose bound is replayed on
+     * the CPU.  scan_mode: 1 matrix cores, 0 vector unit.  mfma_selftest: 1 passed, -1 failed
+     * (fell back), 0 not run (no device, no scan tables, SSW_MFMA_SELFTEST=off). */
+    int32_t scan_mode, mfma_selftest;
+    float mfma_selftest_worst_u; /* worst |D - exact| / sum |terms| seen, in u = 2^-24 */
+    float mfma_selftest_ms;      /* what the self-test added to ssw_model_load */
 } ssw_model_info_t;
 int ssw_model_info(const ssw_model_t *m, ssw_model_info_t *out);
+/* one line on the self-test's outcome ("" when it did not run); owned by the model */
+const char *ssw_model_selftest_message(const ssw_model_t *m);
 
 /* Host copies of the derived tables, for loader parity checks.  Returns a pointer owned by
  * the model and writes the byte size.  Layouts: MEAN/VAR float32 in s3 file order
@@ -187,13 +199,23 @@ int ssw_debug_scan_keys(ssw_model_t *m, const float *d_feats, int32_t n_frames, 
 /* Counters of the last PTM batch: [0] = (chain,frame) pairs the history-free pass could not
  * prove order-independent and handed to the exact sequential pass, [1] = pairs total. */
 int ssw_score_batch_stats(ssw_model_t *m, int64_t stats[2]);
+/* In-process audit of the matrix-core scan (round 5).  With SSW_SCAN_AUDIT=k in the environment
+ * when the model is loaded, every k-th wave of the scan hands ALL of its frames to the exact
+ * in-wave pass -- proven or not -- and compares what the exact pass finds for a pair the scan had
+ * proven with what the scan wrote for it.  stats[0] = proven pairs so audited, stats[1] = of
+ * those, pairs that differ: 0 unless the scan's error bound does not hold on this device (the
+ * load-time self-test of ssw_model_info_t checks the same assumption on synthetic tiles; the
+ * audit checks the claim itself on the caller's data).  Running totals since ssw_model_load;
+ * results are the same with and without the audit.  Cost at k = 1: the scan ~13 x. */
+int ssw_scan_audit_stats(ssw_model_t *m, int64_t stats[2]);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (for bench.py's roofline
  * line).  When enabled every ssw_score_batch call brackets each kernel with events;
- * ssw_get_kernel_timing synchronises and returns the last call's milliseconds:
- * ms[0] = top-N (density) kernel(s), ms[1] = senone kernel -- or, for a batch large enough to be
- * scored in pieces (scan and senone launches alternating), ms[0] = the whole call, ms[1] ~ 0.
- * An event between two launches costs ~2 us of its own.  Returns the number written. */
+ * ssw_get_kernel_timing synchronises and returns the last call's milliseconds.  Return value 2:
+ * ms[0] = top-N (density) kernel(s), ms[1] = senone kernel.  Return value 1 (a batch large
+ * enough to be scored in pieces, scan and senone launches alternating: there is no split):
+ * ms[0] = the whole call (ms[1] is set to 0 when n >= 2).  An event between two launches costs
+ * ~2 us of its own.  -1 on error. */
 int ssw_set_kernel_timing(ssw_model_t *m, int enable);
 int ssw_get_kernel_timing(ssw_model_t *m, float *ms, int n);
 /* measurement aid: `reps` ssw_score_batch calls on the same batch back to back, then one
@@ -540,6 +562,9 @@ void ssw_comm_free(ssw_comm_t *c);
  * on every rank (host memory).  One padded ncclAllGather; synchronous on `stream`. */
 int ssw_gather_alignments(ssw_comm_t *c, const ssw_align_entry_t *local, int32_t n_local,
                           const int32_t *counts, ssw_align_entry_t *out, void *stream);
+/* ncclCommCount of the communicator (the ranks RCCL itself says it spans); n_ranks of a host
+ * transport.  -1 on error. */
+int32_t ssw_comm_count(ssw_comm_t *c);
 
 /* device-memory helpers so a C caller needs no HIP headers */
 void *ssw_device_malloc(size_t nbytes);

@@ -1152,9 +1152,14 @@ ptm_eval_topn(const orc_model_t *m, topn_t *topn, int cb, int feat, const float 
     }
 }
 
-/* eval_cb, src/ptm_mgau.c:150-225 (+ insertion_sort_cb :139-148).  The reference stops the
- * dimension loop early once d < thresh; every term is >= 0 so the early exit only ever skips
- * densities that the final `d < thresh` test rejects as well. */
+/* eval_cb, src/ptm_mgau.c:150-225 (+ insertion_sort_cb :139-148).  The reference walks the
+ * dimensions in stages -- len % 4 single ones, then groups of four -- and leaves the walk as soon
+ * as d < thresh at the head of a stage (:182, :191): "terminated early, so not in topn" (:206-
+ * 211).  For finite features that only skips densities the final `d < thresh` test (:212) would
+ * reject as well (every term is >= 0).  Restated stage by stage all the same (round 5), because
+ * a NaN feature makes the two differ: `d >= thresh` is false for a NaN d, so a density whose d
+ * turns NaN before the last stage is dropped, while one whose d turns NaN IN the last stage
+ * passes `d < thresh` (false again) and is inserted with (int32)NaN -- 0x80000000 on x86. */
 static void
 ptm_eval_cb(const orc_model_t *m, topn_t *topn, int cb, int feat, const float *z)
 {
@@ -1164,9 +1169,26 @@ ptm_eval_cb(const orc_model_t *m, topn_t *topn, int cb, int feat, const float *z
 
     for (cw = 0; cw < m->n_density; ++cw) {
         float thresh = (float)topn[n - 1].score;
-        float d = density(z, m->mean + base + (size_t)cw * len, m->var + base + (size_t)cw * len,
-                          det[cw], len);
+        const float *mean = m->mean + base + (size_t)cw * len;
+        const float *var = m->var + base + (size_t)cw * len;
+        float d = det[cw];
         int32_t s;
+        int j, q;
+        for (j = 0; j < len % 4 && d >= thresh; ++j) {
+            float diff = z[j] - mean[j];
+            float sq = diff * diff;
+            float c = sq * var[j];
+            d = d - c;
+        }
+        for (; j < len && d >= thresh; j += 4)
+            for (q = j; q < j + 4; ++q) {
+                float diff = z[q] - mean[q];
+                float sq = diff * diff;
+                float c = sq * var[q];
+                d = d - c;
+            }
+        if (j < len)
+            continue;
         if (d < thresh)
             continue;
         for (i = 0; i < n; ++i)

@@ -29,7 +29,9 @@ class SswModelInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n_cb", "n_feat", "n_density", "veclen_total", "n_sen", "n_ci_sen", "n_ciphone",
                  "n_phone", "n_emit_state", "n_tmat", "n_sseq", "sil", "n_floored", "topn",
-                 "has_ptm", "has_ms", "device")] + [("veclen", C.c_int32 * 8)]
+                 "has_ptm", "has_ms", "device")] + [
+        ("veclen", C.c_int32 * 8), ("scan_mode", C.c_int32), ("mfma_selftest", C.c_int32),
+        ("mfma_selftest_worst_u", C.c_float), ("mfma_selftest_ms", C.c_float)]
 
 
 class SswAlignEntry(C.Structure):
@@ -91,6 +93,8 @@ def lib() -> C.CDLL:
     L.ssw_model_load.argtypes = [C.c_char_p] * 6 + [C.POINTER(SswConfig)]
     L.ssw_model_free.argtypes = [vp]
     L.ssw_model_info.argtypes = [vp, C.POINTER(SswModelInfo)]
+    L.ssw_model_selftest_message.restype = C.c_char_p
+    L.ssw_model_selftest_message.argtypes = [vp]
     L.ssw_model_table.restype = vp
     L.ssw_model_table.argtypes = [vp, C.c_int, C.POINTER(sz)]
     L.ssw_score_batch.argtypes = [vp, C.c_int, vp, i32, vp, i32, vp, vp]
@@ -99,6 +103,7 @@ def lib() -> C.CDLL:
     L.ssw_score_batch_host.argtypes = [vp, C.c_int, vp, i32, vp, i32, vp]
     L.ssw_score_batch_topn.argtypes = [vp, i32, vp, vp]
     L.ssw_score_batch_stats.argtypes = [vp, vp]
+    L.ssw_scan_audit_stats.argtypes = [vp, vp]
     L.ssw_debug_scan_keys.argtypes = [vp, vp, i32, i32, vp]
     L.ssw_debug_mfma_f16_tiles.argtypes = [vp, vp, vp, vp, vp, i32]
     L.ssw_set_kernel_timing.argtypes = [vp, C.c_int]
@@ -191,6 +196,8 @@ def lib() -> C.CDLL:
     L.ssw_comm_free.argtypes = [vp]
     L.ssw_comm_free.restype = None
     L.ssw_gather_alignments.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.ssw_comm_count.argtypes = [vp]
+    L.ssw_comm_count.restype = i32
     L.ssw_stream_create.restype = vp
     L.ssw_stream_destroy.argtypes = [vp]
     L.ssw_stream_destroy.restype = None

@@ -101,10 +101,13 @@ class Model:
         info = SswModelInfo()
         L.ssw_model_info(self._m, C.byref(info))
         self.info = info
-        for name, _ in SswModelInfo._fields_:
+        for name, ctype in SswModelInfo._fields_:
             if name != "veclen":
-                setattr(self, name, int(getattr(info, name)))
+                setattr(self, name, float(getattr(info, name)) if ctype is C.c_float
+                        else int(getattr(info, name)))
         self.veclen = [int(info.veclen[i]) for i in range(self.n_feat)]
+        # outcome of the matrix-core self-test at load (ssw_amd.h, ssw_model_info_t)
+        self.selftest_message = (L.ssw_model_selftest_message(self._m) or b"").decode()
 
     def close(self):
         if getattr(self, "_m", None):
@@ -217,14 +220,24 @@ class Model:
         _check(self._L.ssw_set_kernel_timing(self._m, int(bool(enable))), "ssw_set_kernel_timing")
 
     def kernel_timing(self):
-        """(topn_ms, senone_ms) of the last score_batch call, from HIP events on its stream."""
+        """(topn_ms, senone_ms) of the last score_batch call, from HIP events on its stream.  For
+        a batch scored in pieces (no split exists) the first number is the whole call and the
+        second 0; `self.timing_split` says which it was."""
         ms = np.zeros(2, np.float32)
-        _check(self._L.ssw_get_kernel_timing(self._m, _ptr(ms), 2), "ssw_get_kernel_timing")
+        n = _check(self._L.ssw_get_kernel_timing(self._m, _ptr(ms), 2), "ssw_get_kernel_timing")
+        self.timing_split = n == 2
         return float(ms[0]), float(ms[1])
 
     def last_stats(self):
         st = np.zeros(2, np.int64)
         self._L.ssw_score_batch_stats(self._m, _ptr(st))
+        return int(st[0]), int(st[1])
+
+    def scan_audit_stats(self):
+        """SSW_SCAN_AUDIT=k: (proven pairs redone exactly by audited waves, of those the pairs
+        whose exact result differs from the scan's), running totals since the model was loaded."""
+        st = np.zeros(2, np.int64)
+        self._L.ssw_scan_audit_stats(self._m, _ptr(st))
         return int(st[0]), int(st[1])
 
     # ---- alignment ----------------------------------------------------------------

@@ -35,8 +35,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <functional>
+#include <map>
 #include <chrono>
 #include <climits>
 #include <cmath>

@@ -54,6 +54,7 @@ class Config5Shard:
         self.tmat = np.concatenate(tmat) if tmat else np.zeros(0, np.int16)
         self.d_feats, self.d_scr = None, None
         self.resident = False
+        self.fallback_note = None
         self.s_score = self.s_align = None
         if self.mine:
             # uploaded chunk by chunk: the host never holds more than one chunk of features
@@ -77,10 +78,12 @@ class Config5Shard:
                              and chunk_utts >= CHUNK_UTTS)
             nbytes = self.chunk_utts * n_frames * model.n_sen * 2
             if self.resident:               # a smaller or shared GPU: fall back to the chunks
+                from .api import SswError
                 try:
                     self.d_scr = model.device_malloc(total)
-                except Exception:           # noqa: BLE001 -- ssw_device_malloc failed
+                except SswError as e:       # hipMalloc said no (ssw_device_malloc clears the error)
                     self.resident = False
+                    self.fallback_note = f"resident allocation of {total} bytes failed ({e}): chunks"
             if not self.resident:
                 self.d_scr = model.device_malloc(2 * nbytes)
             self.d_scr2 = (self.d_scr, self.d_scr + (0 if self.resident else nbytes))
@@ -204,17 +207,21 @@ def run_config5(model, means, dist=None, rank=0, world=1, device=None, reps=2, n
                 dev = device if device is not None else "cpu"
                 tmax = torch.tensor([wall, r["score_s"], r["align_s"], r["gather_s"]],
                                     dtype=torch.float64, device=dev)
+                tmin = tmax.clone()         # the fastest rank's figures: the spread shows imbalance
                 tsum = torch.tensor([float(ok), float(tiles)], dtype=torch.float64, device=dev)
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
                 dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
                 wall, score_s, align_s, gather_s = (float(x) for x in tmax.cpu())
+                lo = [float(x) for x in tmin.cpu()]
                 ok, tiles = int(tsum[0].item()), int(tsum[1].item())
             else:
                 score_s, align_s, gather_s = r["score_s"], r["align_s"], r["gather_s"]
+                lo = [wall, score_s, align_s, gather_s]
             if best is None or wall < best["wall_s"]:
                 best = {"wall_s": wall, "score_s": score_s, "align_s": align_s,
                         "gather_s": gather_s, "aligned": ok, "tiles": tiles == world,
-                        "per_utt": r["per_utt"]}
+                        "min": lo, "per_utt": r["per_utt"]}
     finally:
         shard.close()
     job_frames = n_utts * n_frames
@@ -231,6 +238,10 @@ def run_config5(model, means, dist=None, rank=0, world=1, device=None, reps=2, n
         "n_ranks": world, "n_utts": n_utts,
         "wall_ms": best["wall_s"] * 1e3, "score_ms": best["score_s"] * 1e3,
         "align_ms": best["align_s"] * 1e3, "gather_ms": best["gather_s"] * 1e3,
+        # max over ranks above (what the wall clock waits for); the fastest rank's, for imbalance
+        "per_rank_min": {"wall_ms": best["min"][0] * 1e3, "score_ms": best["min"][1] * 1e3,
+                         "align_ms": best["min"][2] * 1e3, "gather_ms": best["min"][3] * 1e3},
+        "fallback": getattr(shard, "fallback_note", None),
         "job_utt_frames_per_s": job_frames / best["wall_s"],
         "align_rtf": best["wall_s"] / (job_frames / 100.0),
         "aligned": best["aligned"], "alignments_tile_their_utterances": bool(best["tiles"]),

@@ -68,6 +68,10 @@ class RcclComm:
             raise RuntimeError("ssw_gather_alignments: " + _lib.last_error())
         return out
 
+    def count(self) -> int:
+        """ssw_comm_count: the ranks RCCL itself says the communicator spans (ncclCommCount)."""
+        return int(self._L.ssw_comm_count(self._c))
+
     def close(self):
         if getattr(self, "_c", None):
             self._L.ssw_comm_free(self._c)

@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 MODEL_ROOT = os.path.join(ROOT, "soundswallower_amd", "model")
 
+# The library reads its SSW_* tuning knobs once, at ssw_model_load (csrc/ssw_host_model.inc,
+# Knobs); the knob tests flip them between calls on one session-wide model, so they ask for the
+# knobs to be re-read on every call.  Must be set before libssw_amd.so is loaded.
+os.environ.setdefault("SSW_KNOBS_DYNAMIC", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")

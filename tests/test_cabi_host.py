@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert len(names) >= 30
     for n in names:
         assert hasattr(lib, n), f"{n} is declared in include/ssw_amd.h but not exported"
-    assert lib.ssw_abi_version() == 1
+    assert lib.ssw_abi_version() == 2
 
 
 def test_header_cites_reference_interfaces():

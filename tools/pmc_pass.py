@@ -31,7 +31,7 @@ SETS = [["FETCH_SIZE"], ["WRITE_SIZE"],
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
     os.chdir(ROOT)
     env = dict(os.environ, TMPDIR="/tmp", SSW_BENCH_NO_SPIN="1")
     per = collections.defaultdict(dict)
