@@ -307,6 +307,48 @@ int ssw_align_batch_active_ex(ssw_model_t *m, int scorer, const float *d_feats, 
                               const int32_t *ef, const uint32_t *seed_active,
                               ssw_align_entry_t *state_io, int32_t *status, int16_t *d_senscr,
                               void *stream);
+/* Compact score rows (NEW, round 5).  state_align_search only ever reads the scores of its own
+ * phones' senones -- it activates just those (src/state_align_search.c:186-189), and in the
+ * default configuration acmod then scores nothing else (src/acmod.c:905-945).  When the phone
+ * strings of a batch are known before it is scored (BASELINE configs 3 and 5; the second pass of
+ * decoder_alignment, whose phones come from alignment_populate), a PLAN lets the scorer store,
+ * per utterance, rows of that utterance's states only -- [n_frames_u][3 n_phones_u rounded up to
+ * even] int16 instead of [n_frames_u][n_sen]: 0.9 KB instead of 10 KB per frame for a 150-phone
+ * utterance of en-us -- which the alignment kernel then reads coalesced instead of gathering
+ * three scattered 2-byte values per phone from rows it touches nearly every sector of.  Every
+ * senone is still evaluated (compallsen = yes: the frame's best score is taken over all of
+ * them, src/ptm_mgau.c:394-400): the scores, and so the alignments, are those of
+ * ssw_score_batch + ssw_align_batch bit for bit.  A senone several states of an utterance
+ * share is stored once, at the first of them.
+ *   ssw_compact_plan_create   frame_off / phone_off / senid as ssw_align_batch takes them (host);
+ *                             builds the device tables on `stream` and returns when they are
+ *                             complete.  Utterances of up to 10,922 phones.
+ *   ssw_compact_plan_elems    int16 elements the compact buffer needs (the caller allocates it)
+ *   ssw_compact_plan_rows     utterance u's rows: offset (elements) and row length in the buffer;
+ *                             state k of the utterance (3 per phone) at column k, or at the
+ *                             column of the first state with the same senone
+ *   ssw_score_batch_compact   ssw_score_batch_ex for the plan's batch (utterance offsets = the
+ *                             plan's frame_off; history reset per utterance), asynchronous on
+ *                             `stream`; flags: SSW_SCORE_SHARE_DEVICE
+ *   ssw_align_batch_compact   ssw_align_batch over those rows (tmatid, sf, ef, state_io, status
+ *                             as there; the utterances, phones and senones are the plan's)
+ * A plan is bound to its model and can be used any number of times. */
+typedef struct ssw_compact_plan_s ssw_compact_plan_t;
+ssw_compact_plan_t *ssw_compact_plan_create(ssw_model_t *m, int32_t n_utts,
+                                            const int32_t *frame_off, const int32_t *phone_off,
+                                            const uint16_t *senid, void *stream);
+void ssw_compact_plan_free(ssw_compact_plan_t *plan);
+size_t ssw_compact_plan_elems(const ssw_compact_plan_t *plan);
+int ssw_compact_plan_rows(const ssw_compact_plan_t *plan, int32_t utt, long long *row_off,
+                          int32_t *stride);
+int ssw_score_batch_compact(ssw_model_t *m, int scorer, const float *d_feats,
+                            const ssw_compact_plan_t *plan, int16_t *d_compact, void *stream,
+                            uint32_t flags);
+int ssw_align_batch_compact(ssw_model_t *m, const ssw_compact_plan_t *plan,
+                            const int16_t *d_compact, const int16_t *tmatid, const int32_t *sf,
+                            const int32_t *ef, ssw_align_entry_t *state_io, int32_t *status,
+                            void *stream);
+
 /* alignment_propagate (src/ps_alignment.c:316-352): sums children into parents.
  * parent[i] = index of child i's parent; parents must appear in non-decreasing order. */
 int ssw_alignment_propagate(const ssw_align_entry_t *child, const int32_t *parent,

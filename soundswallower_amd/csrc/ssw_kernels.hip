@@ -26,6 +26,8 @@
  *                        src/state_align_search.c:177-268, src/hmm.c:482-567)
  *   ssw_k5_firstpass.inc first_pass_kernel (fsg_search start/step/finish over the linear
  *                        grammar's phone trees, src/fsg_search.c:665-925)
+ *   ssw_k6_compact.inc   compact score rows: the plan of a batch of alignments (which of an
+ *                        utterance's states share a senone, where each score goes), gather
  *   ssw_host_*.inc       device model and loaders' upload, batched scoring, alignment, the
  *                        mgau_t / search-module shaped objects, features, device-memory helpers,
  *                        the RCCL gather of final alignments (ssw_host_comm.inc)
@@ -71,12 +73,14 @@ namespace {
 #include "ssw_k4_feat.inc"
 #include "ssw_k2_align.inc"
 #include "ssw_k5_firstpass.inc"
+#include "ssw_k6_compact.inc"
 
 } // namespace
 
 #include "ssw_host_model.inc"
 #include "ssw_host_score.inc"
 #include "ssw_host_align.inc"
+#include "ssw_host_compact.inc"
 #include "ssw_host_active.inc"
 #include "ssw_host_mgau.inc"
 #include "ssw_host_search.inc"

@@ -13,6 +13,7 @@ of the job have committed checksums.
 from __future__ import annotations
 
 import ctypes
+import os
 import time
 import zlib
 
@@ -55,6 +56,12 @@ class Config5Shard:
         self.d_feats, self.d_scr = None, None
         self.resident = False
         self.fallback_note = None
+        # Round 5: compact score rows (include/ssw_amd.h).  The phone strings are known before
+        # the shard is scored, so the scorer stores each utterance's own 450 states' scores only
+        # (0.9 KB instead of 10 KB per frame: 1.8 GB instead of 21 GB for the whole job) and the
+        # alignment kernel reads them coalesced.  SSW_JOB_ROWS=full keeps rounds 3-4's full rows.
+        self.compact = os.environ.get("SSW_JOB_ROWS", "compact") != "full"
+        self.d_compact = None
         self.s_score = self.s_align = None
         if self.mine:
             # uploaded chunk by chunk: the host never holds more than one chunk of features
@@ -70,6 +77,15 @@ class Config5Shard:
             # 2048 (six waves per SIMD instead of one) -- so eight calls beside the scoring of the
             # next chunk (each three times slower for sharing the chip, and slowing the scoring)
             # cost more than one call at the end.  Beyond RESIDENT_BYTES: chunks, ping-pong.
+            if self.compact:
+                self.frame_off = (np.arange(len(self.mine) + 1) * n_frames).astype(np.int32)
+                self.phone_off = (np.arange(len(self.mine) + 1) * n_phones).astype(np.int32)
+                self.d_compact = model.device_malloc(
+                    len(self.mine) * n_frames * ((3 * n_phones + 1) & ~1) * 2)
+                self.resident = True
+                self.s_score = model._L.ssw_stream_create()
+                self.s_align = model._L.ssw_stream_create()
+                return
             total = len(self.mine) * n_frames * model.n_sen * 2
             free_b = ctypes.c_size_t(0)
             if model._L.ssw_device_mem_info(ctypes.byref(free_b), None) != 0:
@@ -91,10 +107,10 @@ class Config5Shard:
             self.s_align = model._L.ssw_stream_create()
 
     def close(self):
-        for p in (self.d_feats, self.d_scr):
+        for p in (self.d_feats, self.d_scr, self.d_compact):
             if p:
                 self.model.device_free(p)
-        self.d_feats = self.d_scr = None
+        self.d_feats = self.d_scr = self.d_compact = None
         for st in (self.s_score, self.s_align):
             if st:
                 self.model._L.ssw_stream_destroy(st)
@@ -116,6 +132,22 @@ class Config5Shard:
         chunks = [(c0, min(n_mine, c0 + self.chunk_utts)) for c0 in range(0, n_mine, self.chunk_utts)]
         if not chunks:
             return states, status, 0.0, 0.0
+        if self.compact:
+            # the plan (which states each utterance reads, where their scores go) is part of the
+            # job: built inside the timed region, counted with the scoring
+            ta = time.perf_counter()
+            plan = m.compact_plan(self.frame_off, self.phone_off, self.senid, stream=self.s_score)
+            try:
+                assert plan.nbytes == n_mine * F * ((3 * P + 1) & ~1) * 2
+                m.score_batch_compact(self.d_feats, plan, self.d_compact, self.s_score)
+                L.ssw_stream_synchronize(self.s_score)
+                tb = time.perf_counter()
+                st, stat = m.align_batch_compact(plan, self.d_compact, self.tmat,
+                                                 stream=self.s_align)
+                tc = time.perf_counter()
+            finally:
+                plan.free()
+            return st, stat, tb - ta, tc - tb
         if self.resident:
             frame_off = (np.arange(n_mine + 1) * F).astype(np.int32)
             phone_off = (np.arange(n_mine + 1) * P).astype(np.int32)
@@ -230,7 +262,10 @@ def run_config5(model, means, dist=None, rank=0, world=1, device=None, reps=2, n
     return {
         "workload": f"{n_utts} utterances x {n_frames} frames x {n_phones} phones, en-us, dealt "
                     f"over {world} rank(s), "
-                    + ("every shard scored as a whole and aligned in one call"
+                    + ("every shard scored as a whole into compact rows (its utterances' own "
+                       "states only) and aligned in one call"
+                       if getattr(shard, "compact", False)
+                       else "every shard scored as a whole and aligned in one call"
                        if getattr(shard, "resident", False)
                        else f"in chunks of {shard.chunk_utts} utterances")
                     + ": PTM scoring + forced alignment per rank, one gather of the state "

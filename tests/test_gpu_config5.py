@@ -91,7 +91,7 @@ def test_c_gather_entry_point_one_rank(gpu_en):
         comm.close()
 
 
-def test_chunk_size_does_not_change_the_alignments(gpu_en, means_en):
+def test_chunk_size_does_not_change_the_alignments(gpu_en, means_en, monkeypatch):
     """a rank's shard is scored and aligned in chunks, scoring a chunk ahead of
     alignment on a stream of its own into two ping-pong score buffers; the alignments must not
     depend on the cut.  A 256-utterance shard (what one of 8 ranks holds) through chunks of 32,
@@ -100,11 +100,15 @@ def test_chunk_size_does_not_change_the_alignments(gpu_en, means_en):
     DESIGN.md section 6.)"""
     from soundswallower_amd import jobs
     crcs, walls = {}, {}
-    for chunk in (32, 64, 100, 256):
+    # (round 5: the job's default is compact score rows, scored and aligned as a whole; the
+    # chunked full-row path of rounds 2-4 stays behind SSW_JOB_ROWS=full and must agree with it)
+    for chunk in (32, 64, 100, 256, "compact"):
+        monkeypatch.setenv("SSW_JOB_ROWS", "compact" if chunk == "compact" else "full")
         shard = jobs.Config5Shard(gpu_en, means_en, rank=0, world=1, n_utts=256, n_frames=1000,
-                                  n_phones=150, chunk_utts=chunk)
+                                  n_phones=150, chunk_utts=256 if chunk == "compact" else chunk)
         try:
-            assert shard.chunk_utts == chunk
+            assert shard.compact == (chunk == "compact")
+            assert chunk == "compact" or shard.chunk_utts == chunk
             shard.run()
             r = shard.run()
         finally:
