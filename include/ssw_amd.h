@@ -276,6 +276,15 @@ int ssw_align_batch(ssw_model_t *m, const int16_t *d_senscr, int32_t n_utts,
                     const int32_t *frame_off, const int32_t *phone_off, const uint16_t *senid,
                     const int16_t *tmatid, const int32_t *sf, const int32_t *ef,
                     ssw_align_entry_t *state_io, int32_t *status, void *stream);
+/* How the last alignments were made (round 5).  Utterances of up to 1024 phones first go through
+ * a kernel that keeps, per state and frame, a 2-bit back-pointer instead of the reference's
+ * {history, score} token (src/state_align_search.c:149-175) and recovers the scores the backtrace
+ * needs by replaying the path; what that kernel cannot follow -- the reference's stale-exit-score
+ * and left-over-t2 cases (src/hmm.c:496-520), a backtrace that runs into a missing token -- it
+ * hands, untouched, to the kernel with the full tokens.  stats[0] = utterances that took the
+ * byte-token kernel, stats[1] = of those, the ones that were handed on; running totals since
+ * ssw_model_load.  Results are the same either way; SSW_ALIGN_BT=0 skips the first kernel. */
+int ssw_align_stats(ssw_model_t *m, int64_t stats[2]);
 /* The same search in the reference's DEFAULT configuration (compallsen = no), scoring included:
  * acmod scores only the senones of the HMMs the search has active (acmod_activate_hmm /
  * acmod_flags2list, src/acmod.c:905-999 -- a uint8 delta list whose gaps above 255 list extra

@@ -104,6 +104,7 @@ def lib() -> C.CDLL:
     L.ssw_score_batch_topn.argtypes = [vp, i32, vp, vp]
     L.ssw_score_batch_stats.argtypes = [vp, vp]
     L.ssw_scan_audit_stats.argtypes = [vp, vp]
+    L.ssw_align_stats.argtypes = [vp, vp]
     L.ssw_compact_plan_create.restype = vp
     L.ssw_compact_plan_create.argtypes = [vp, i32, vp, vp, vp, vp]
     L.ssw_compact_plan_free.argtypes = [vp]

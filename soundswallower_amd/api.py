@@ -240,6 +240,13 @@ class Model:
         self._L.ssw_scan_audit_stats(self._m, _ptr(st))
         return int(st[0]), int(st[1])
 
+    def align_stats(self):
+        """(utterances through the byte-token alignment kernel, of those handed on to the
+        full-token kernel), running totals"""
+        st = np.zeros(2, np.int64)
+        self._L.ssw_align_stats(self._m, _ptr(st))
+        return int(st[0]), int(st[1])
+
     # ---- alignment ----------------------------------------------------------------
     def align_batch(self, d_senscr, frame_off, phone_off, senid, tmatid, sf=None, ef=None,
                     state_init=None, stream=None):

@@ -28,9 +28,9 @@ def soak_align(a):
     t0 = time.time()
     n_utts = n_fail = bad = n_frames = n_batches = 0
     while time.time() - t0 < a.seconds:
-        mode = ["mw", "reg", "lds", "hbm", "win"][n_batches % 5]
+        mode = ["mw", "reg", "lds", "hbm", "win", "mwb", "mwb"][n_batches % 7]
         os.environ["SSW_ALIGN_KERNEL"] = mode
-        os.environ["SSW_ALIGN_WIN_WAVES"] = ["2", "4", "8"][(n_batches // 5) % 3]
+        os.environ["SSW_ALIGN_WIN_WAVES"] = ["2", "4", "8"][(n_batches // 7) % 3]
         n_batches += 1
         k = int(rng.integers(1, 7))
         n_ph = rng.integers(1, 300, size=k).tolist()
@@ -73,6 +73,8 @@ def soak_align(a):
             n_frames += n_fr[i]
     print(json.dumps({"mode": "align", "utterances": n_utts, "frames": n_frames,
                       "utterances_without_a_path": int(n_fail), "utterances_differing": bad,
+                      "byte_token_kernel": dict(zip(("utterances", "handed_to_full_tokens"),
+                                                    g.align_stats())),
                       "seconds": round(time.time() - t0, 1)}))
     sys.exit(1 if bad else 0)
 

@@ -71,7 +71,7 @@ def test_all_alignment_kernels_agree_on_a_ragged_windowed_batch(gpu_en, orc_en, 
     try:
         results = []
         monkeypatch.setenv("SSW_ALIGN_WIN_WAVES", "2")   # "win": a window of 2 blocks that slides
-        for mode in ("mw", "reg", "lds", "hbm", "win"):
+        for mode in ("mw", "reg", "lds", "hbm", "win", "mwb"):
             monkeypatch.setenv("SSW_ALIGN_KERNEL", mode)
             results.append(gpu_en.align_batch(d, frame_off, phone_off, senid, tmat, sf=sf, ef=ef))
     finally:
@@ -86,9 +86,10 @@ def test_all_alignment_kernels_agree_on_a_ragged_windowed_batch(gpu_en, orc_en, 
     assert np.array_equal(results[0][1], results[2][1])
     assert np.array_equal(results[0][1], results[3][1])
     assert np.array_equal(results[0][1], results[4][1])
+    assert np.array_equal(results[0][1], results[5][1])
 
 
-@pytest.mark.parametrize("mode", ["reg", "lds", "hbm"])
+@pytest.mark.parametrize("mode", ["mw", "reg", "lds", "hbm"])
 def test_other_alignment_kernels_match_oracle(gpu_en, orc_en, monkeypatch, mode):
     monkeypatch.setenv("SSW_ALIGN_KERNEL", mode)
     for n_phones, n_frames in ((64, 300), (65, 300), (150, 700), (256, 900)):
@@ -128,7 +129,7 @@ def test_skip_arc_topologies_match_oracle(orc_en, oracle_mod, monkeypatch, tmp_p
     assert np.array_equal(g.table("tp"), o.tp.reshape(-1))
     tp = o.tp
     assert (tp[:, 0, 2] < 255).any() and (tp[:, 0, 2] == 255).any() and (tp[:, 1, 3] < 255).any()
-    for mode in ("mw", "reg", "lds", "hbm"):
+    for mode in ("mw", "reg", "lds", "hbm", "mwb"):
         monkeypatch.setenv("SSW_ALIGN_KERNEL", mode)
         for n_phones, n_frames in ((6, 30), (70, 260), (150, 500)):
             senid, tmat, _ = synth_alignment_task(o.sseq, o.phone_ssid, o.phone_tmat, o.n_ciphone,
@@ -336,3 +337,57 @@ def test_fall_back_reruns_only_what_failed_from_the_callers_state(gpu_en, orc_en
             n_bad += 1
             assert np.array_equal(st[s3], init[s3]), (u, shapes[u])   # untouched
     assert n_ok >= 5 and n_bad >= 1
+
+
+def test_byte_token_kernel_hands_on_what_it_cannot_replay(gpu_en, orc_en):
+    """viterbi_align_mwb_kernel (2-bit back-pointers + score replay, the default up to 1024 phones)
+    must give the reference's entries or hand the utterance, untouched, to the full-token kernel.
+    Ordinary problems: nothing handed on.  Windows that END a phone while its predecessor lives
+    on, so that it is entered again with states 1 and 2 still holding their old scores
+    (hmm_enter only sets state 0, src/hmm.c:142-148): handed on, and still equal to the oracle."""
+    rng = np.random.default_rng(123)
+    before = gpu_en.align_stats()
+    test_align_matches_oracle(gpu_en, orc_en, 150, 700)
+    mid = gpu_en.align_stats()
+    assert mid[0] == before[0] + 1 and mid[1] == before[1]
+    n_utts, seen_ok = 24, 0
+    n_ph = rng.integers(4, 140, size=n_utts).tolist()
+    n_fr = [int(p * rng.integers(3, 6) + 6) for p in n_ph]
+    frame_off = np.concatenate([[0], np.cumsum(n_fr)]).astype(np.int32)
+    phone_off = np.concatenate([[0], np.cumsum(n_ph)]).astype(np.int32)
+    scr = _random_senscr(int(frame_off[-1]), orc_en.n_sen, 99)
+    senid, tmat, sf, ef = [], [], [], []
+    for u, (p, f) in enumerate(zip(n_ph, n_fr)):
+        s_, t_, _ = synth_alignment_task(orc_en.sseq, orc_en.phone_ssid, orc_en.phone_tmat,
+                                         orc_en.n_ciphone, p, 4000 + u)
+        senid.append(s_)
+        tmat.append(t_)
+        mid_ = (np.arange(p) * f) // p
+        a = np.maximum(mid_ - 8, 0).astype(np.int32)
+        b = np.minimum(mid_ + f // p + 10, f).astype(np.int32)
+        # every third phone's window closes early while its neighbours' stay open: it drops out
+        # and is entered again (and again) from its predecessor
+        b[1::3] = np.maximum(a[1::3] + 2, mid_[1::3] - 2)
+        b[-1] = f
+        sf.append(a)
+        ef.append(b)
+    senid, tmat = np.concatenate(senid), np.concatenate(tmat)
+    sf, ef = np.concatenate(sf), np.concatenate(ef)
+    d = gpu_en.to_device(scr)
+    try:
+        st, status = gpu_en.align_batch(d, frame_off, phone_off, senid, tmat, sf=sf, ef=ef)
+    finally:
+        gpu_en.device_free(d)
+    after = gpu_en.align_stats()
+    assert after[0] == mid[0] + n_utts
+    for u in range(n_utts):
+        sl = slice(phone_off[u], phone_off[u + 1])
+        rv, rst, _ = orc_en.state_align(scr[frame_off[u]:frame_off[u + 1]], senid[sl], tmat[sl],
+                                        sf=sf[sl], ef=ef[sl])
+        assert (status[u] == 0) == (rv == 0), u
+        if rv == 0:
+            seen_ok += 1
+            assert np.array_equal(st[phone_off[u] * 3:phone_off[u + 1] * 3], rst), u
+    print("handed on to the full-token kernel: %d of %d (aligned: %d)"
+          % (after[1] - mid[1], n_utts, seen_ok))
+    assert after[1] > mid[1], "the windows were meant to make some utterances irregular"
