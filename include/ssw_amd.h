@@ -340,7 +340,11 @@ int ssw_align_batch_active_ex(ssw_model_t *m, int scorer, const float *d_feats, 
  *                             plan's frame_off; history reset per utterance), asynchronous on
  *                             `stream`; flags: SSW_SCORE_SHARE_DEVICE
  *   ssw_align_batch_compact   ssw_align_batch over those rows (tmatid, sf, ef, state_io, status
- *                             as there; the utterances, phones and senones are the plan's)
+ *                             as there; the utterances, phones and senones are the plan's);
+ *                             flags: SSW_ALIGN_STATE_OUT_ONLY -- state_io is output only, the
+ *                             entries the backtrace does not write (states a path skips,
+ *                             utterances without an alignment) come back as zeros instead of
+ *                             what the caller passed in: saves the upload of 36 bytes per phone
  * A plan is bound to its model and can be used any number of times. */
 typedef struct ssw_compact_plan_s ssw_compact_plan_t;
 ssw_compact_plan_t *ssw_compact_plan_create(ssw_model_t *m, int32_t n_utts,
@@ -356,7 +360,8 @@ int ssw_score_batch_compact(ssw_model_t *m, int scorer, const float *d_feats,
 int ssw_align_batch_compact(ssw_model_t *m, const ssw_compact_plan_t *plan,
                             const int16_t *d_compact, const int16_t *tmatid, const int32_t *sf,
                             const int32_t *ef, ssw_align_entry_t *state_io, int32_t *status,
-                            void *stream);
+                            void *stream, uint32_t flags);
+#define SSW_ALIGN_STATE_OUT_ONLY 1u
 
 /* alignment_propagate (src/ps_alignment.c:316-352): sums children into parents.
  * parent[i] = index of child i's parent; parents must appear in non-decreasing order. */

@@ -113,7 +113,7 @@ def lib() -> C.CDLL:
     L.ssw_compact_plan_elems.restype = sz
     L.ssw_compact_plan_rows.argtypes = [vp, i32, vp, vp]
     L.ssw_score_batch_compact.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_uint32]
-    L.ssw_align_batch_compact.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ssw_align_batch_compact.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32]
     L.ssw_debug_scan_keys.argtypes = [vp, vp, i32, i32, vp]
     L.ssw_debug_mfma_f16_tiles.argtypes = [vp, vp, vp, vp, vp, i32]
     L.ssw_set_kernel_timing.argtypes = [vp, C.c_int]

@@ -127,13 +127,17 @@ class Model:
         return np.frombuffer(buf, dtype=dtype).copy()
 
     # ---- scoring ------------------------------------------------------------------
-    def score_batch(self, feats, utt_off=None, scorer=SCORER_PTM) -> np.ndarray:
-        """Score host features [n_frames][39]; returns int16 [n_frames][n_sen]."""
+    def score_batch(self, feats, utt_off=None, scorer=SCORER_PTM, out=None) -> np.ndarray:
+        """Score host features [n_frames][39]; returns int16 [n_frames][n_sen] (`out`, if given:
+        a caller that scores batch after batch reuses one buffer instead of faulting in 10 KB
+        of fresh pages per frame)."""
         feats = np.ascontiguousarray(feats, dtype=np.float32).reshape(-1, self.veclen_total)
         n = feats.shape[0]
         off = (np.array([0, n], np.int32) if utt_off is None
                else np.ascontiguousarray(utt_off, np.int32))
-        out = np.zeros((n, self.n_sen), np.int16)
+        if out is None:
+            out = np.zeros((n, self.n_sen), np.int16)
+        assert out.dtype == np.int16 and out.shape == (n, self.n_sen) and out.flags.c_contiguous
         _check(self._L.ssw_score_batch_host(self._m, scorer, _ptr(feats), n, _ptr(off),
                                             len(off) - 1, _ptr(out)), "ssw_score_batch_host")
         return out
@@ -310,19 +314,21 @@ class Model:
 
     def align_batch_compact(self, plan, d_compact, tmatid, sf=None, ef=None, state_init=None,
                             stream=None):
-        """ssw_align_batch_compact; returns (states[n,3] int32, status[n_utts])."""
+        """ssw_align_batch_compact; returns (states[n,3] int32, status[n_utts]).  Without
+        state_init the entries are output only (SSW_ALIGN_STATE_OUT_ONLY: nothing uploaded)."""
         n_ph = plan.total_phones
         tmatid = np.ascontiguousarray(tmatid, np.int16)
         assert len(tmatid) == n_ph
         sf = np.zeros(n_ph, np.int32) if sf is None else np.ascontiguousarray(sf, np.int32)
         ef = (np.full(n_ph, INT_MAX, np.int32) if ef is None
               else np.ascontiguousarray(ef, np.int32))
-        states = (np.zeros((n_ph * 3, 3), np.int32) if state_init is None
+        states = (np.empty((n_ph * 3, 3), np.int32) if state_init is None
                   else np.ascontiguousarray(state_init, np.int32).copy())
         status = np.zeros(plan.n_utts, np.int32)
         _check(self._L.ssw_align_batch_compact(self._m, plan._p, _ptr(d_compact), _ptr(tmatid),
                                                _ptr(sf), _ptr(ef), _ptr(states), _ptr(status),
-                                               C.c_void_p(int(stream)) if stream else None),
+                                               C.c_void_p(int(stream)) if stream else None,
+                                               1 if state_init is None else 0),
                "ssw_align_batch_compact")
         return states, status
 

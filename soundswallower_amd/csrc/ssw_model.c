@@ -1139,6 +1139,21 @@ ssw_host_build_mfma_records(ssw_host_model_t *h)
                         break;
                     cs = nextafterf(cs, INFINITY);
                 }
+                if (back < ldexp(cc, -(s + ec))) {
+                    /* 64 float steps do not always reach a value the two binary16
+                     * parts hold from above -- below 2^-7 the second part is a binary16
+                     * subnormal on a 2^-24 grid, hundreds of float ulps wide -- and a key that
+                     * is not a proven upper bound is the one failure the exact pass cannot
+                     * catch.  Such a density (constant nearly cancelled: none in en-us / fr-fr,
+                     * whose smallest |c'| is 0.38) goes on the exact-form list instead. */
+                    inert[d] = 1;
+                    xl[1 + xl[0]++] = (uint32_t)d;
+                    for (j = 0; j < SSW_MAX_VECLEN; ++j)
+                        q[j] = q[SSW_REC_VAR + j] = 0.0f;
+                    q[SSW_REC_DET] = -3.0e38f;
+                    ++h->n_exact_form_m;
+                    continue;
+                }
                 cf = (float)ldexp(back, s + ec);
                 if ((double)cf < ldexp(back, s + ec))
                     cf = nextafterf(cf, INFINITY);

@@ -331,3 +331,46 @@ def test_mfma_scan_bound_on_a_hostile_model(tmp_path):
     assert n_pairs > 20_000 and worst_use < 1.0
     print(f"hostile: {n_pairs} pairs, {int(exm[:, 0].sum())} of {n_cbf * m.n_density} densities exact-form, "
           f"min margin {worst_margin:.4g}, share of the widening used {worst_use:.3f}")
+
+
+def test_mfma_constant_that_nearly_cancels(tmp_path):
+    """a density whose constant c' = (det - d0 - sum var mean^2 + bias) 2^-(s + ec) is
+    tiny -- one variance for every density (det = d0) and means of a few thousandths -- has a
+    second binary16 part on the subnormal grid (2^-24), which 64 float steps upwards do not
+    always reach; the host must then either hold the constant from above with its two parts or
+    leave the density to the exact form.  Either way the replayed bound must hold."""
+    from tests.test_cabi_host import _write_s3
+    import struct
+    rng = np.random.default_rng(41)
+    n_cb, n_feat, nd, vl = 3, 3, 128, 13
+    mean = (rng.standard_normal((n_cb, n_feat, nd, vl)) * 3.0e-3).astype("<f4")
+    mean[1] *= 30.0                                   # one codebook of ordinary size beside them
+    var = np.full((n_cb, n_feat, nd, vl), 0.7, "<f4")
+    var[2] = np.exp(rng.uniform(np.log(0.5), np.log(0.9), (n_feat, nd, vl))).astype("<f4")
+    paths = {}
+    for nm, arr in (("means", mean), ("variances", var)):
+        payload = struct.pack("<3i", n_cb, n_feat, nd) + struct.pack(f"<{n_feat}i", *([vl] * n_feat))
+        payload += struct.pack("<i", arr.size) + arr.tobytes()
+        paths[nm] = str(tmp_path / nm)
+        _write_s3(paths[nm], payload)
+    m = ssw.Model(config={"device": -2}, **paths)
+    n_cbf = m.n_cb * m.n_feat
+    mean4 = m.table("rec").reshape(m.n_cb, m.n_feat, m.n_density, 32)[:, :, :, 0:13]
+    W, d0, scale, xconst = mfma_operands(m)
+    exm = m.table("scan_exact_mfma").reshape(n_cbf, 132)
+    rm = m.table("scan_rec_mfma").reshape(n_cbf, nd, 32)
+    # the constants the matrix cores see, back in score units, against what the record says
+    small = 0
+    for cbf in range(n_cbf):
+        live = np.ones(nd, bool)
+        live[exm[cbf, 1:1 + exm[cbf, 0]]] = False
+        c_parts = (W[cbf, 0, :, 15].astype(np.float64) + W[cbf, 1, :, 15].astype(np.float64))
+        small += int((np.abs(c_parts[live]) < 2.0 ** -7).sum())
+        back = c_parts * float(scale[cbf]) * float(xconst[cbf])
+        assert np.array_equal(back[live].astype(np.float32), rm[cbf, live, 15])
+    rng = np.random.default_rng(6)
+    n_pairs, worst_margin, worst_use = _mfma_bound_without_the_adder(m, mean4, rng, "tiny constants",
+                                                                     n_in=96, min_live=0)
+    print(f"tiny constants: {small} live constants below 2^-7 after scaling, {n_pairs} pairs, "
+          f"{int(exm[:, 0].sum())} densities exact-form, min margin {worst_margin:.4g}")
+    assert n_pairs > 20_000 and worst_margin >= 0.0

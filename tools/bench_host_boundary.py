@@ -24,19 +24,65 @@ def main():
     for utts in (16, 256):
         feats = np.concatenate([synth_features(means, 256, 12345 + u) for u in range(utts)])
         off = (np.arange(utts + 1) * 256).astype(np.int32)
+        n = len(feats)
+        rows = np.zeros((n, m.n_sen), np.int16)       # the caller's buffer, reused call after call
         for _ in range(3):
-            m.score_batch(feats, off)
+            m.score_batch(feats, off, out=rows)
         reps = 20 if utts == 16 else 5
         t0 = time.perf_counter()
         for _ in range(reps):
-            m.score_batch(feats, off)
+            m.score_batch(feats, off, out=rows)
         dt = (time.perf_counter() - t0) / reps
-        n = len(feats)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m.score_batch(feats, off)                 # a fresh (zeroed, untouched) buffer per call
+        dt_fresh = (time.perf_counter() - t0) / reps
+        # a ragged stream of batches: every call other utterance offsets (the uploads of the
+        # offsets and start bits), against the same frames with fixed offsets
+        rng = np.random.default_rng(utts)
+        offs = []
+        for _ in range(reps):
+            cuts = np.sort(rng.choice(np.arange(1, n), size=utts - 1, replace=False))
+            offs.append(np.concatenate([[0], cuts, [n]]).astype(np.int32))
+        t0 = time.perf_counter()
+        for o in offs:
+            m.score_batch(feats, o, out=rows)
+        dt_ragged = (time.perf_counter() - t0) / reps
         out[f"frames_{n}"] = {"ms_per_call": dt * 1e3, "frames_per_s": n / dt,
+                              "frames_per_s_fresh_output_buffer": n / dt_fresh,
+                              "frames_per_s_new_offsets_every_call": n / dt_ragged,
                               "host_bytes_per_call": int(feats.nbytes + n * m.n_sen * 2),
                               "effective_GBps": (feats.nbytes + n * m.n_sen * 2) / dt / 1e9}
-    out["note"] = ("ssw_score_batch_host: pageable host buffers, hipMemcpy in, two kernels, "
-                   "hipMemcpy out (10,252 B of scores per frame against 156 B of features)")
+    # the device-resident call on a ragged stream: new offsets every call against fixed ones
+    import ctypes as C
+    feats = np.concatenate([synth_features(means, 256, 12345 + u) for u in range(16)])
+    n = len(feats)
+    d_feats = m.to_device(feats)
+    d_out = m.device_malloc(n * m.n_sen * 2)
+    rng = np.random.default_rng(7)
+    offs = []
+    for _ in range(200):
+        cuts = np.sort(rng.choice(np.arange(1, n), size=15, replace=False))
+        offs.append(np.concatenate([[0], cuts, [n]]).astype(np.int32))
+    fixed = (np.arange(17) * 256).astype(np.int32)
+    res = {}
+    for name, seq in (("fixed_offsets", [fixed] * 200), ("new_offsets_every_call", offs)):
+        for o in seq[:20]:
+            m.score_batch_device(d_feats, n, o, d_out)
+        m._L.ssw_device_synchronize()
+        t0 = time.perf_counter()
+        for o in seq:
+            m.score_batch_device(d_feats, n, o, d_out)
+        m._L.ssw_device_synchronize()
+        res[name] = n * len(seq) / (time.perf_counter() - t0)
+    m.device_free(d_feats)
+    m.device_free(d_out)
+    out["device_resident_4096_frames"] = dict(res, ragged_over_fixed=res["new_offsets_every_call"]
+                                              / res["fixed_offsets"])
+    out["note"] = ("ssw_score_batch_host: host buffers; round 5: sub-batches of ~4096 frames "
+                   "through pinned staging, scoring / download / host copy overlapped (10,252 B "
+                   "of scores per frame against 156 B of features); device_resident: "
+                   "ssw_score_batch, 4096 frames per call, through the Python binding")
     print(json.dumps(out))
 
 
