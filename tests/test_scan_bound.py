@@ -343,10 +343,14 @@ def test_mfma_constant_that_nearly_cancels(tmp_path):
     import struct
     rng = np.random.default_rng(41)
     n_cb, n_feat, nd, vl = 3, 3, 128, 13
+    # the constant's scale 2^ec is per codebook x stream: half of every codebook's densities
+    # share the reference variance and sit at the origin (constant = the bias alone), the other
+    # half have constants in the hundreds and set the scale
     mean = (rng.standard_normal((n_cb, n_feat, nd, vl)) * 3.0e-3).astype("<f4")
-    mean[1] *= 30.0                                   # one codebook of ordinary size beside them
     var = np.full((n_cb, n_feat, nd, vl), 0.7, "<f4")
-    var[2] = np.exp(rng.uniform(np.log(0.5), np.log(0.9), (n_feat, nd, vl))).astype("<f4")
+    mean[:, :, nd // 2:] = (rng.standard_normal((n_cb, n_feat, nd // 2, vl)) * 4.0).astype("<f4")
+    var[:, :, nd // 2:] = np.exp(rng.uniform(np.log(0.7), np.log(6.0),
+                                             (n_cb, n_feat, nd // 2, vl))).astype("<f4")
     paths = {}
     for nm, arr in (("means", mean), ("variances", var)):
         payload = struct.pack("<3i", n_cb, n_feat, nd) + struct.pack(f"<{n_feat}i", *([vl] * n_feat))
