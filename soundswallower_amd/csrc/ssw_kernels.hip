@@ -41,6 +41,7 @@
 #include <atomic>
 #include <functional>
 #include <map>
+#include <set>
 #include <chrono>
 #include <climits>
 #include <cmath>

@@ -35,6 +35,7 @@ def word_windows(rng, n_phones, n_frames):
         ef[i:i + g] = min(n_frames, t + dur + 8)
         t += dur
         i += g
+    ef[-1] = n_frames          # the last phone lives to the end of the audio
     return sf, np.maximum.accumulate(ef)
 
 
