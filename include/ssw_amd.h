@@ -19,13 +19,16 @@
  * a compute call that finds another thread inside one on the same model fails with "the model is
  * in use by another thread" instead of sharing its workspaces.
  *
- * Inputs: parity with the reference is claimed for FINITE features.  A NaN or infinity in a
- * feature row is not refused (checking every row would cost a pass over the batch): every
- * (codebook, stream) pair it touches fails the scan's proof test and is scored by the exact
- * in-wave pass, whose float -> int conversions then follow the GPU's rules (saturating, NaN ->
- * 0) where the reference's `(int32)` casts follow the host CPU's (x86: 0x80000000) -- the
- * scores of such a frame are defined, but not the reference's.  Hosts that cannot rule
- * non-finite cepstra out should screen them before ssw_feat_batch / ssw_score_batch.
+ * Inputs: non-finite features are not refused (checking every row would cost a pass over the
+ * batch); every (codebook, stream) pair they touch fails the scan's proof test and is scored by
+ * the exact in-wave pass.  PTM scorer (round 5): that pass does what the reference does with
+ * them -- its (int32) casts of a NaN are x86's 0x80000000, and eval_cb's staged dimension walk
+ * (src/ptm_mgau.c:150-225) drops every density of a stream with a NaN in dimensions 0..8 while
+ * a NaN confined to the last four dimensions lets densities through with INT32_MIN -- so NaN
+ * and +-Inf rows score as in the reference (tests/test_gpu_nonfinite.py, against the oracle
+ * compiled on x86).  ms scorer: infinities likewise; with a NaN the reference's compute_dist
+ * (src/ms_gauden.c:397-420) leaves its top-N entries as they were, i.e. reads the PREVIOUS
+ * frame's ids from its buffer -- a result no batch can reproduce and none is claimed.
  * Range: any finite feature gives the reference's scores, but the fast path of the scoring
  * kernels (the matrix-core scan, binary16 operands) only trusts frames whose features lie
  * within +-255 -- cepstral features of the shipped front end are a tenth of that; a frame
