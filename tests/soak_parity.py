@@ -12,6 +12,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file lives in tests/)
 sys.path.insert(0, ROOT)
+# the soaks flip kernel knobs between batches on one model: have the library re-read them per call
+os.environ.setdefault("SSW_KNOBS_DYNAMIC", "1")
 import soundswallower_amd as ssw  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from soundswallower_amd.synth import read_raw_means, synth_features  # noqa: E402
@@ -335,6 +337,12 @@ def main():
                       "frames_by_kind": kinds, "rows_differing": bad_rows,
                       "frames_with_topn_order_differing": bad_topn,
                       "exact_pass_share": flagged / max(pairs, 1),
+                      # SSW_SCAN_AUDIT=k in the environment: proven pairs redone exactly by the
+                      # audited waves of the matrix-core scan, and how many of them differed
+                      "scan_audit": dict(zip(("k", "proven_pairs_audited", "pairs_differing"),
+                                             (int(os.environ.get("SSW_SCAN_AUDIT", "0")),)
+                                             + g.scan_audit_stats())),
+                      "mfma_selftest_worst_u": g.mfma_selftest_worst_u,
                       "seconds": round(time.time() - t0, 1)}))
     sys.exit(1 if bad_rows or bad_topn else 0)
 

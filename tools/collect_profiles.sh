@@ -1,10 +1,10 @@
 #!/bin/bash
 # Everything the round's profiles/ files come from, in one call ON the GPU box:
-#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r04'
+#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r05'
 # Writes gpurun_out/<tag>/; copy what is to be judged into profiles/<tag>_* afterwards
 # (tools/collect_profiles.sh does not touch profiles/).  rocprofv3 gets `python3 <script>` directly
 # after `--` (no shell, no env in between) and --pmc passes are never combined with other traces.
-tag=${1:-r04}
+tag=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
@@ -26,6 +26,8 @@ prof headline python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no
 prof full python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline
 prof config4 python3 $R/tools/bench_ms.py
 prof config3_align python3 $R/tools/bench_align.py
+prof config5_align python3 $R/tools/bench_align.py --utts 2048 --reps 2
+prof align_active python3 $R/tools/bench_align_active.py --reps 2
 prof first_pass python3 $R/tools/bench_first_pass.py --reps 5
 prof page python3 $R/tools/bench_page.py
 cd $R
@@ -36,4 +38,14 @@ timeout 300 python tools/bench_frame_sync.py > $O/frame_sync.json 2>/dev/null
 timeout 300 python tools/bench_first_pass.py --reps 5 > $O/first_pass.json 2>/dev/null
 timeout 300 python tools/bench_ms.py > $O/config4_ms.json 2>/dev/null
 timeout 300 python tools/bench_align.py > $O/config3_align.json 2>/dev/null
+timeout 300 python tools/bench_align.py --utts 2048 > $O/config5_align.json 2>/dev/null
+SSW_JOB_ROWS=full SSW_ALIGN_BT=0 timeout 300 python tools/bench_align.py --utts 2048 > $O/config5_align_full_rows_full_tokens.json 2>/dev/null
+timeout 300 python tools/bench_align_active.py > $O/align_active.json 2>/dev/null
+timeout 300 python tools/bench_align_active.py --ms > $O/align_active_ms.json 2>/dev/null
+timeout 300 python tools/bench_host_boundary.py > $O/host_boundary.json 2>/dev/null
+# counters of the alignment kernel on compact rows + byte tokens, and on the round-4 form
+timeout 900 python3 tools/pmc_cmd.py gpurun_out/$tag/align_pmc_2048.json 'viterbi_align\w+|ptm_senone_kernel|ptm_topn_mfma_kernel' -- python3 tools/bench_align.py --utts 2048 --reps 1 > $O/align_pmc_2048.log 2>&1
+timeout 900 python3 tools/pmc_cmd.py gpurun_out/$tag/align_pmc_256.json 'viterbi_align\w+' -- python3 tools/bench_align.py --utts 256 --reps 1 > $O/align_pmc_256.log 2>&1
+timeout 900 python3 tools/pmc_cmd.py gpurun_out/$tag/align_active_pmc.json 'senone_active2_kernel|viterbi_align\w+' -- python3 tools/bench_align_active.py --reps 1 > $O/align_active_pmc.log 2>&1
+rm -rf $R/gpurun_out/pmc_align_pmc_2048 $R/gpurun_out/pmc_align_pmc_256 $R/gpurun_out/pmc_align_active_pmc
 ls $O

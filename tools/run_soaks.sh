@@ -2,11 +2,15 @@
 # Randomised GPU-vs-oracle soaks on the current build (ON the GPU box):
 #   gpurun --timeout 3000 -- 'bash tools/run_soaks.sh r04 240'
 # Writes gpurun_out/<tag>_parity_soak_*.json (copy into profiles/ to keep them).
-tag=${1:-r04}
+tag=${1:-r05}
 secs=${2:-240}
 O=$GRAFT_REPO_ROOT/gpurun_out
 cd $GRAFT_REPO_ROOT
 python tests/soak_parity.py --mode ptm --seconds $secs > $O/${tag}_parity_soak_ptm.json 2> $O/${tag}_soak_ptm.err
+# the same with every third wave of the matrix-core scan audited in-kernel (and every wave)
+SSW_SCAN_AUDIT=3 python tests/soak_parity.py --mode ptm --seconds $((secs / 2)) > $O/${tag}_parity_soak_ptm_audit3.json 2> $O/${tag}_soak_ptm_audit3.err
+SSW_SCAN_AUDIT=1 python tests/soak_parity.py --mode ptm --max-len 3000 --seconds $((secs / 2)) > $O/${tag}_parity_soak_ptm_audit1_long.json 2> $O/${tag}_soak_ptm_audit1_long.err
+SSW_SCAN_AUDIT=2 python tests/soak_parity.py --mode ms --model fr-fr --seconds $((secs / 2)) > $O/${tag}_parity_soak_ms_audit2.json 2> $O/${tag}_soak_ms_audit2.err
 python tests/soak_parity.py --mode ptm --model fr-fr --seconds $((secs / 2)) > $O/${tag}_parity_soak_ptm_frfr.json 2> $O/${tag}_soak_ptm_frfr.err
 python tests/soak_parity.py --mode ms --model fr-fr --seconds $secs > $O/${tag}_parity_soak_ms.json 2> $O/${tag}_soak_ms.err
 python tests/soak_parity.py --mode align --seconds $secs > $O/${tag}_parity_soak_align.json 2> $O/${tag}_soak_align.err
