@@ -43,6 +43,10 @@ SSW_JOB_ROWS=full SSW_ALIGN_BT=0 timeout 300 python tools/bench_align.py --utts 
 timeout 300 python tools/bench_align_active.py > $O/align_active.json 2>/dev/null
 timeout 300 python tools/bench_align_active.py --ms > $O/align_active_ms.json 2>/dev/null
 timeout 300 python tools/bench_host_boundary.py > $O/host_boundary.json 2>/dev/null
+# texts of ~300 words (2,000-4,000 phone-tree HMMs: first_pass_kernel<2,1024> / <4,1024>, the
+# instances with scratch) against the sliding-window kernel on the same texts
+timeout 300 python tools/bench_first_pass.py --utts 32 --words 300 --frames 12000 --reps 2 > $O/first_pass_300_words.json 2>/dev/null
+SSW_FP_KERNEL=big timeout 300 python tools/bench_first_pass.py --utts 32 --words 300 --frames 12000 --reps 2 > $O/first_pass_300_words_window_kernel.json 2>/dev/null
 # counters of the alignment kernel on compact rows + byte tokens, and on the round-4 form
 timeout 900 python3 tools/pmc_cmd.py gpurun_out/$tag/align_pmc_2048.json 'viterbi_align\w+|ptm_senone_kernel|ptm_topn_mfma_kernel' -- python3 tools/bench_align.py --utts 2048 --reps 1 > $O/align_pmc_2048.log 2>&1
 timeout 900 python3 tools/pmc_cmd.py gpurun_out/$tag/align_pmc_256.json 'viterbi_align\w+' -- python3 tools/bench_align.py --utts 256 --reps 1 > $O/align_pmc_256.log 2>&1
