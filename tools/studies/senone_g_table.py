@@ -15,9 +15,12 @@ with a packed add that wraps per half.  This script checks on random and extreme
 the chain so written returns exactly fast_logmath_add's values plus T k, and that the halves
 never interfere.  Per pair and step it costs what the present form costs (two differences, two
 look-ups, two packed adds instead of packed min + add3); what it saves is 9 of the 18 packed adds
-of a quad and frame (120 vector instructions today).  Open: ds_read_u16_d16_hi's treatment of
-the low half on gfx950 (the u8 form zeroes it), bank conflicts of a 2-byte table, and a model
-whose weights pass 159 (needs the present kernel as a fall-back).
+of a quad and frame (120 vector instructions today).  Round 5, on the device side: NOT
+worth building.  A 2-byte table is read at byte address 2 d; the SDWA subtracts deliver d, and
+every way of doubling it (a shift per look-up, a packed subtract + two v_mad_u32_u16, the whole
+chain in doubled units -- which needs the spread weights doubled, the packed instruction this
+was to remove) costs per look-up what the byte-domain add saves per pair (DESIGN.md, round 5,
+item 9).
 
     python tools/studies/senone_g_table.py
 """
