@@ -116,6 +116,15 @@ class Model:
 
     __del__ = close
 
+    @property
+    def tmat_n_emit(self) -> int:
+        """Emitting states of the transition matrices (3 for both shipped models; 1, 2, 4 or 5
+        take hmm_vit_eval's other branches, viterbi_align_any_kernel)."""
+        if getattr(self, "_tmat_ne", None) is None:
+            per = self.table("tp").size // max(self.n_tmat, 1)       # ne * (ne + 1) bytes a matrix
+            self._tmat_ne = next((ne for ne in range(1, 17) if ne * (ne + 1) == per), 3)
+        return self._tmat_ne
+
     def table(self, name: str) -> np.ndarray:
         """Host copy of a derived table (flat), for loader parity checks."""
         which, dtype = _TABLES[name]
@@ -254,16 +263,19 @@ class Model:
     # ---- alignment ----------------------------------------------------------------
     def align_batch(self, d_senscr, frame_off, phone_off, senid, tmatid, sf=None, ef=None,
                     state_init=None, stream=None):
-        """Viterbi forced alignment of a batch; returns (states[n,3] int32, status[n_utts])."""
+        """Viterbi forced alignment of a batch; returns (states[n,3] int32, status[n_utts]).
+        senid: [total_phones][n_emit] (n_emit = the transition matrices', 3 unless the model says
+        otherwise)."""
+        ne = self.tmat_n_emit
         frame_off = np.ascontiguousarray(frame_off, np.int32)
         phone_off = np.ascontiguousarray(phone_off, np.int32)
-        senid = np.ascontiguousarray(senid, np.uint16).reshape(-1, 3)
+        senid = np.ascontiguousarray(senid, np.uint16).reshape(-1, ne)
         n_ph = senid.shape[0]
         tmatid = np.ascontiguousarray(tmatid, np.int16)
         sf = np.zeros(n_ph, np.int32) if sf is None else np.ascontiguousarray(sf, np.int32)
         ef = (np.full(n_ph, INT_MAX, np.int32) if ef is None
               else np.ascontiguousarray(ef, np.int32))
-        states = (np.zeros((n_ph * 3, 3), np.int32) if state_init is None
+        states = (np.zeros((n_ph * ne, 3), np.int32) if state_init is None
                   else np.ascontiguousarray(state_init, np.int32).copy())
         n_utts = len(frame_off) - 1
         status = np.zeros(n_utts, np.int32)

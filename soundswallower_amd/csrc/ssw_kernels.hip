@@ -24,6 +24,8 @@
  *   ssw_k2_align.inc     viterbi_align_mw_kernel / _reg_kernel / viterbi_align_kernel
  *                        (state_align_search step/finish + hmm_vit_eval_3st_lr,
  *                        src/state_align_search.c:177-268, src/hmm.c:482-567)
+ *   ssw_k2_anytopo.inc   viterbi_align_any_kernel: the same search over HMMs of 1, 2, 4 or 5 states
+ *                        (hmm_vit_eval_5st_lr, hmm_vit_eval_anytopo, src/hmm.c:166-304, :671-739)
  *   ssw_k5_firstpass.inc first_pass_kernel (fsg_search start/step/finish over the linear
  *                        grammar's phone trees, src/fsg_search.c:665-925)
  *   ssw_k6_compact.inc   compact score rows: the plan of a batch of alignments (which of an
@@ -73,6 +75,7 @@ namespace {
 #include "ssw_k1b_senone.inc"
 #include "ssw_k4_feat.inc"
 #include "ssw_k2_align.inc"
+#include "ssw_k2_anytopo.inc"
 #include "ssw_k5_firstpass.inc"
 #include "ssw_k6_compact.inc"
 
