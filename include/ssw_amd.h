@@ -274,7 +274,11 @@ typedef struct ssw_align_entry_s {
  *                                           entries (src/ps_alignment.c:237-239); out: backtrace
  *   status    int32 [n_utts]                0 ok, -1 "Failed to reach final state",
  *                                           -(2+frame) "Alignment failed in frame"
- * All host pointers except d_senscr.  Synchronous. */
+ * All host pointers except d_senscr.  Synchronous.
+ * n_emit is the transition matrices' (hmm_vit_eval, src/hmm.c:741-759): 3 takes
+ * hmm_vit_eval_3st_lr in the kernels this library is built around; 5 (hmm_vit_eval_5st_lr) and
+ * 1, 2, 4 (hmm_vit_eval_anytopo) take one plain kernel, a wave per utterance.  More than
+ * HMM_MAX_NSTATE = 5 states is refused, as hmm_context_init does (src/hmm.c:60-64). */
 int ssw_align_batch(ssw_model_t *m, const int16_t *d_senscr, int32_t n_utts,
                     const int32_t *frame_off, const int32_t *phone_off, const uint16_t *senid,
                     const int16_t *tmatid, const int32_t *sf, const int32_t *ef,
