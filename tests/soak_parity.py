@@ -81,6 +81,70 @@ def soak_align(a):
     sys.exit(1 if bad else 0)
 
 
+def soak_topo(a):
+    """HMMs of 1, 2, 4 and 5 emitting states (hmm_vit_eval_5st_lr / hmm_vit_eval_anytopo through
+    viterbi_align_any_kernel): models made on the spot as in tests/test_gpu_topologies.py, random
+    ragged batches with random windows, against the oracle."""
+    import pathlib
+    import tempfile
+    from soundswallower_amd.synth import lcg_uniform
+    from tests.test_gpu_topologies import _models, _task
+    tmp = pathlib.Path(tempfile.mkdtemp(prefix="ssw_topo_"))
+    models = {ne: _models(tmp, O, ne) for ne in (5, 4, 2, 1)}
+    rng = np.random.default_rng(78)
+    t0 = time.time()
+    n_utts = n_fail = bad = n_frames = n_batches = 0
+    per_ne = {ne: 0 for ne in models}
+    while time.time() - t0 < a.seconds:
+        ne = (5, 4, 5, 2, 5, 1)[n_batches % 6]
+        g, o, tp = models[ne]
+        n_batches += 1
+        k = int(rng.integers(1, 7))
+        n_ph = rng.integers(1, 200, size=k).tolist()
+        n_fr = [int(p * rng.integers(max(ne - 1, 1), ne + 4) + rng.integers(0, 9)) for p in n_ph]
+        frame_off = np.concatenate([[0], np.cumsum(n_fr)]).astype(np.int32)
+        phone_off = np.concatenate([[0], np.cumsum(n_ph)]).astype(np.int32)
+        seed = int(rng.integers(1, 2**31))
+        u = lcg_uniform(seed, int(frame_off[-1]) * o.n_sen).reshape(-1, o.n_sen)
+        scr = np.floor(u * rng.choice([60, 600, 6000])).astype(np.int16)
+        senid, tmat, sf, ef = [], [], [], []
+        for i, (p, f) in enumerate(zip(n_ph, n_fr)):
+            s_, t_, _ = _task(o, ne, p, seed % 100000 + i)
+            senid.append(s_)
+            tmat.append(t_)
+            lo = np.zeros(p, np.int32)
+            hi = np.full(p, 2**31 - 1, np.int32)
+            if rng.random() < 0.5:
+                mid = (np.arange(p) * f) // p
+                slack = int(rng.integers(0, 12))
+                lo = np.maximum(mid - slack, 0).astype(np.int32)
+                hi = np.minimum(mid + f // p + slack + 1, f).astype(np.int32)
+            sf.append(lo)
+            ef.append(hi)
+        senid, tmat = np.concatenate(senid), np.concatenate(tmat)
+        sf, ef = np.concatenate(sf), np.concatenate(ef)
+        d = g.to_device(scr)
+        st, status = g.align_batch(d, frame_off, phone_off, senid, tmat, sf=sf, ef=ef)
+        g.device_free(d)
+        for i in range(k):
+            sl = slice(phone_off[i], phone_off[i + 1])
+            rv, rst, _ = o.state_align(scr[frame_off[i]:frame_off[i + 1]], senid[sl], tmat[sl],
+                                       sf=sf[sl], ef=ef[sl], tp=tp)
+            if (status[i] == 0) != (rv == 0):
+                bad += 1
+            elif rv == 0 and not np.array_equal(st[phone_off[i] * ne:phone_off[i + 1] * ne], rst):
+                bad += 1
+            n_fail += rv != 0
+            n_utts += 1
+            per_ne[ne] += 1
+            n_frames += n_fr[i]
+    print(json.dumps({"mode": "topo", "utterances": n_utts, "frames": n_frames,
+                      "utterances_by_states": {str(k_): v for k_, v in per_ne.items()},
+                      "utterances_without_a_path": int(n_fail), "utterances_differing": bad,
+                      "seconds": round(time.time() - t0, 1)}))
+    sys.exit(1 if bad else 0)
+
+
 def soak_first_pass(a):
     """Random texts (1-12 words), synthetic scores that follow one path through the text's phone
     trees with noise at random levels (clean, near-ties, wrong turns, no path), ragged batches:
@@ -254,7 +318,7 @@ def main():
                     help="text mode: words per text (hundreds: the sliding windows of the "
                          "long-text kernels move, every other batch)")
     ap.add_argument("--model", default="en-us")
-    ap.add_argument("--mode", default="ptm", choices=["ptm", "ms", "align", "first_pass", "text"])
+    ap.add_argument("--mode", default="ptm", choices=["ptm", "ms", "align", "topo", "first_pass", "text"])
     ap.add_argument("--max-len", type=int, default=400,
                     help="ptm / ms: utterances of up to this many frames, 1-5 per batch (the "
                          "matrix-core scan takes batches from ~2100 frames: use 1600)")
@@ -263,6 +327,8 @@ def main():
         return soak_first_pass(a)
     if a.mode == "text":
         return soak_text(a)
+    if a.mode == "topo":
+        return soak_topo(a)
     if a.mode == "align":
         return soak_align(a)
     mdir = ssw.model_dir(a.model)

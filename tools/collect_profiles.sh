@@ -51,5 +51,7 @@ SSW_FP_KERNEL=big timeout 300 python tools/bench_first_pass.py --utts 32 --words
 timeout 900 python3 tools/pmc_cmd.py gpurun_out/$tag/align_pmc_2048.json 'viterbi_align\w+|ptm_senone_kernel|ptm_topn_mfma_kernel' -- python3 tools/bench_align.py --utts 2048 --reps 1 > $O/align_pmc_2048.log 2>&1
 timeout 900 python3 tools/pmc_cmd.py gpurun_out/$tag/align_pmc_256.json 'viterbi_align\w+' -- python3 tools/bench_align.py --utts 256 --reps 1 > $O/align_pmc_256.log 2>&1
 timeout 900 python3 tools/pmc_cmd.py gpurun_out/$tag/align_active_pmc.json 'senone_active2_kernel|viterbi_align\w+' -- python3 tools/bench_align_active.py --reps 1 > $O/align_active_pmc.log 2>&1
+# the senone kernel's selectable shapes on the headline workload
+timeout 600 bash tools/bench_sen_shapes.sh $tag > $O/sen_shapes.log 2>&1
 rm -rf $R/gpurun_out/pmc_align_pmc_2048 $R/gpurun_out/pmc_align_pmc_256 $R/gpurun_out/pmc_align_active_pmc
 ls $O

@@ -14,6 +14,7 @@ SSW_SCAN_AUDIT=2 python tests/soak_parity.py --mode ms --model fr-fr --seconds $
 python tests/soak_parity.py --mode ptm --model fr-fr --seconds $((secs / 2)) > $O/${tag}_parity_soak_ptm_frfr.json 2> $O/${tag}_soak_ptm_frfr.err
 python tests/soak_parity.py --mode ms --model fr-fr --seconds $secs > $O/${tag}_parity_soak_ms.json 2> $O/${tag}_soak_ms.err
 python tests/soak_parity.py --mode align --seconds $secs > $O/${tag}_parity_soak_align.json 2> $O/${tag}_soak_align.err
+python tests/soak_parity.py --mode topo --seconds $((secs / 2)) > $O/${tag}_parity_soak_topo.json 2> $O/${tag}_soak_topo.err
 python tests/soak_parity.py --mode first_pass --seconds $secs > $O/${tag}_parity_soak_first_pass.json 2> $O/${tag}_soak_first_pass.err
 python tests/soak_parity.py --mode first_pass --model fr-fr --seconds $secs > $O/${tag}_parity_soak_first_pass_frfr.json 2> $O/${tag}_soak_first_pass_frfr.err
 python tests/soak_parity.py --mode text --seconds $secs > $O/${tag}_parity_soak_text.json 2> $O/${tag}_soak_text.err
