@@ -192,7 +192,8 @@ def test_text_and_audio_to_the_reference_json(oracle_mod, gpu_en):
 
 def test_long_texts_use_the_wider_kernels(oracle_mod, gpu_en, orc_en):
     """Texts of 60, 150 and 330 words: more than 512 / 1024 / 2048 phone-tree HMMs, i.e. the
-    1024-thread instances with one, two and four HMMs per thread; same results as the oracle."""
+    1024-thread register kernel and, beyond 1,024 HMMs, the sliding-window kernel (rounds 1-4:
+    register instances with two and four HMMs per thread); same results as the oracle."""
     F, olex = _olex(oracle_mod, orc_en, "en-us")
     lex = _lex(gpu_en, "en-us")
     vocab = [w for w in olex.order[:olex.filler_start] if "(" not in w]
