@@ -1,5 +1,8 @@
 #!/bin/bash
-# first pass: register kernels (1, 2, 4 HMMs per thread) against the sliding-window kernel by text length
+# First pass by text length (ON the GPU box): the default kernel choice against the sliding-window
+# kernel forced (SSW_FP_KERNEL=big), 32 and 256 texts of 60..400 words.  Round 5 ran it with the
+# register instances of 2 and 4 HMMs per thread still in place: they
+# lost from ~1,200 HMMs up and were removed; now both columns read the same beyond 1,024 HMMs.
 O=gpurun_out/r05o; mkdir -p $O
 for w in 60 100 120 160 200 250 300 400; do
   fr=$((w * 40))
