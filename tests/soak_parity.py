@@ -26,7 +26,7 @@ def soak_align(a):
     from soundswallower_amd.synth import lcg_uniform, synth_alignment_task
     mdir = ssw.model_dir(a.model)
     g, o = ssw.Model(mdir), O.Model(mdir)
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + a.seed)
     t0 = time.time()
     n_utts = n_fail = bad = n_frames = n_batches = 0
     while time.time() - t0 < a.seconds:
@@ -73,7 +73,7 @@ def soak_align(a):
             n_fail += rv != 0
             n_utts += 1
             n_frames += n_fr[i]
-    print(json.dumps({"mode": "align", "utterances": n_utts, "frames": n_frames,
+    print(json.dumps({"mode": "align", "seed": a.seed, "utterances": n_utts, "frames": n_frames,
                       "utterances_without_a_path": int(n_fail), "utterances_differing": bad,
                       "byte_token_kernel": dict(zip(("utterances", "handed_to_full_tokens"),
                                                     g.align_stats())),
@@ -91,7 +91,7 @@ def soak_topo(a):
     from tests.test_gpu_topologies import _models, _task
     tmp = pathlib.Path(tempfile.mkdtemp(prefix="ssw_topo_"))
     models = {ne: _models(tmp, O, ne) for ne in (5, 4, 2, 1)}
-    rng = np.random.default_rng(78)
+    rng = np.random.default_rng(78 + a.seed)
     t0 = time.time()
     n_utts = n_fail = bad = n_frames = n_batches = 0
     per_ne = {ne: 0 for ne in models}
@@ -138,7 +138,7 @@ def soak_topo(a):
             n_utts += 1
             per_ne[ne] += 1
             n_frames += n_fr[i]
-    print(json.dumps({"mode": "topo", "utterances": n_utts, "frames": n_frames,
+    print(json.dumps({"mode": "topo", "seed": a.seed, "utterances": n_utts, "frames": n_frames,
                       "utterances_by_states": {str(k_): v for k_, v in per_ne.items()},
                       "utterances_without_a_path": int(n_fail), "utterances_differing": bad,
                       "seconds": round(time.time() - t0, 1)}))
@@ -160,7 +160,7 @@ def soak_first_pass(a):
     lex = ssw.Lexicon(m, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
     olex = F.Lexicon(orc, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
     vocab = [w for w in olex.order[:olex.filler_start] if "(" not in w]
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(2024 + a.seed)
     t_end = time.time() + a.seconds
     n_utts = n_frames = n_fail = n_batches = n_label = 0
     while time.time() < t_end:
@@ -249,7 +249,7 @@ def soak_text(a):
             lc = p[-1]
         return out
 
-    rng = np.random.default_rng(4711)
+    rng = np.random.default_rng(4711 + a.seed)
     t_end = time.time() + a.seconds
     n_utts = n_frames = n_fail = n_batches = 0
     while time.time() < t_end:
@@ -318,6 +318,8 @@ def main():
                     help="text mode: words per text (hundreds: the sliding windows of the "
                          "long-text kernels move, every other batch)")
     ap.add_argument("--model", default="en-us")
+    ap.add_argument("--seed", type=int, default=0,
+                    help="added to the mode's own seed: another run, other inputs")
     ap.add_argument("--mode", default="ptm", choices=["ptm", "ms", "align", "topo", "first_pass", "text"])
     ap.add_argument("--max-len", type=int, default=400,
                     help="ptm / ms: utterances of up to this many frames, 1-5 per batch (the "
@@ -353,7 +355,7 @@ def main():
     else:
         g, o = ssw.Model(mdir), O.Model(mdir)
     means = read_raw_means(mdir)
-    rng = np.random.default_rng(20261002)
+    rng = np.random.default_rng(20261002 + a.seed)
     t0 = time.time()
     n_frames = n_batches = bad_rows = bad_topn = flagged = pairs = 0
     kinds = {}
@@ -398,7 +400,7 @@ def main():
         flagged += f
         pairs += p
         kinds[kind] = kinds.get(kind, 0) + n
-    print(json.dumps({"mode": a.mode, "model": a.model, "max_len": a.max_len,
+    print(json.dumps({"mode": a.mode, "seed": a.seed, "model": a.model, "max_len": a.max_len,
                       "batches": n_batches, "frames": n_frames,
                       "frames_by_kind": kinds, "rows_differing": bad_rows,
                       "frames_with_topn_order_differing": bad_topn,
