@@ -292,6 +292,7 @@ def self_launch(n_ranks):
     procs = []
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                    LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                                       env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
@@ -321,12 +322,21 @@ def self_launch(n_ranks):
                 p_.wait(timeout=10)
             except subprocess.TimeoutExpired:
                 p_.kill()
-    sys.stdout.write(out0)
+    # ONE JSON line on stdout: whatever else rank 0's libraries printed there (gloo's "Rank 0 is
+    # connected to ..." for one) goes to stderr
+    line = ""
+    for ln in out0.splitlines():
+        if ln.startswith("{") and ln.rstrip().endswith("}"):
+            line = ln
+        elif ln.strip():
+            sys.stderr.write(ln + "\n")
+    if line:
+        sys.stdout.write(line + "\n")
     sys.stdout.flush()
     if rc:
         raise SystemExit(f"bench.py: a rank of the self-launched {n_ranks}-rank job exited with "
                          f"code {rc}")
-    if not out0.strip():
+    if not line:
         raise SystemExit("bench.py: rank 0 printed no line")
 
 
