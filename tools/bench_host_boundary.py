@@ -79,7 +79,7 @@ def main():
     m.device_free(d_out)
     out["device_resident_4096_frames"] = dict(res, ragged_over_fixed=res["new_offsets_every_call"]
                                               / res["fixed_offsets"])
-    out["note"] = ("ssw_score_batch_host: host buffers; round 5: sub-batches of ~4096 frames "
+    out["note"] = ("ssw_score_batch_host: host buffers; round 5: sub-batches of ~1024 frames "
                    "through pinned staging, scoring / download / host copy overlapped (10,252 B "
                    "of scores per frame against 156 B of features); device_resident: "
                    "ssw_score_batch, 4096 frames per call, through the Python binding")
