@@ -286,9 +286,13 @@ def self_launch(n_ranks):
     rank 0's JSON line and exit non-zero if any rank does."""
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    # (the port is free now and claimed by rank 0's store a moment later; a caller that needs a
+    # fixed one sets SSW_BENCH_MASTER_PORT)
+    port = int(os.environ.get("SSW_BENCH_MASTER_PORT", "0"))
+    if port == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
     procs = []
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks),
@@ -297,22 +301,32 @@ def self_launch(n_ranks):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                                       env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
                                       text=True))
-    rc, out0 = 0, ""
+    # Rank 0's stdout is drained on a thread while ALL ranks are polled: a rank that dies early
+    # (bad device, import error, out of memory) would otherwise leave rank 0 waiting in
+    # init_process_group or a collective until the process group's own timeout, minutes later
+    # (ADVICE r5).  The first non-zero exit ends the job: the rest are terminated.
+    import threading
+    rc, chunks = 0, []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    limit = float(os.environ.get("SSW_BENCH_LAUNCH_TIMEOUT", "3600"))
+    t_end = time.time() + limit
     try:
-        out0 = procs[0].communicate()[0] or ""      # rank 0 prints the line when the job is done
         pending = list(procs)
-        t_end = time.time() + 120.0                  # the others are past their last collective
-        while pending:
+        while pending and not rc:
             for p_ in list(pending):
                 code = p_.poll()
                 if code is not None:
                     pending.remove(p_)
-                    rc = rc or code
-            if rc or time.time() > t_end:
-                break
-            time.sleep(0.05)
-        if pending:
-            rc = rc or 1
+                    if code and not rc:
+                        rc = code
+                        sys.stderr.write(f"bench.py: rank {procs.index(p_)} exited with code "
+                                         f"{code}; stopping the other ranks\n")
+            if time.time() > t_end:
+                sys.stderr.write(f"bench.py: ranks still running after {limit:.0f} s\n")
+                rc = rc or 1
+            if pending and not rc:
+                time.sleep(0.05)
     finally:
         for p_ in procs:                             # exactly the processes started above
             if p_.poll() is None:
@@ -322,6 +336,9 @@ def self_launch(n_ranks):
                 p_.wait(timeout=10)
             except subprocess.TimeoutExpired:
                 p_.kill()
+                p_.wait()
+        reader.join(timeout=10)
+    out0 = "".join(c or "" for c in chunks)
     # ONE JSON line on stdout: whatever else rank 0's libraries printed there (gloo's "Rank 0 is
     # connected to ..." for one) goes to stderr
     line = ""

@@ -180,7 +180,12 @@ int ssw_score_batch(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_
 int ssw_score_batch_ex(ssw_model_t *m, int scorer, const float *d_feats, int32_t n_frames,
                        const int32_t *utt_off, int32_t n_utts, int16_t *d_out, void *stream,
                        uint32_t flags, const uint32_t *carry_in, uint32_t *carry_out);
-/* host pointers, synchronous: copies in, scores, copies out */
+/* host pointers, synchronous: copies in, scores, copies out -- as a three-stage pipeline over
+ * sub-batches of whole utterances (~1024 frames) through pinned staging.  History reset per
+ * utterance.  An utterance of more than 16,384 frames (SSW_HOST_PIPE_CAP) is scored in pieces
+ * of that many that hand the history on, so the staging the model keeps for this call stops at
+ * 2 x 16,384 feature rows + score rows pinned on the host and as many on the device (en-us:
+ * 2 x 171 MB each), however long the utterances are. */
 int ssw_score_batch_host(ssw_model_t *m, int scorer, const float *feats, int32_t n_frames,
                          const int32_t *utt_off, int32_t n_utts, int16_t *out);
 /* Debug/parity view of the PTM top-N state after normalisation for every frame of the last
@@ -304,7 +309,11 @@ int ssw_align_stats(ssw_model_t *m, int64_t stats[2]);
  * windows alignment_populate produces); otherwise the call is refused.  d_feats: feature rows
  * [total_frames][veclen_total]; d_senscr: optional int16 [total_frames][n_sen] that receives
  * the scores exactly as acmod->senone_scores would hold them frame by frame.  Other arguments
- * and results as ssw_align_batch.  PTM scorer, history reset per utterance. */
+ * and results as ssw_align_batch.  PTM scorer, history reset per utterance.
+ * Limits (the call aligns over compact score rows, see below): 3-state HMMs, at most 64
+ * codebooks, utterances of at most 10,922 phones (a row's per-state indices are 16 bits) --
+ * beyond them the call is refused with an error; ssw_score_batch + ssw_align_batch take any
+ * length but are the compallsen = yes configuration, i.e. other scores. */
 int ssw_align_batch_active(ssw_model_t *m, const float *d_feats, int32_t n_utts,
                            const int32_t *frame_off, const int32_t *phone_off,
                            const uint16_t *senid, const int16_t *tmatid, const int32_t *sf,

@@ -325,17 +325,23 @@ class Model:
                                                2 if share_device else 0), "ssw_score_batch_compact")
 
     def align_batch_compact(self, plan, d_compact, tmatid, sf=None, ef=None, state_init=None,
-                            stream=None):
+                            stream=None, out=None):
         """ssw_align_batch_compact; returns (states[n,3] int32, status[n_utts]).  Without
-        state_init the entries are output only (SSW_ALIGN_STATE_OUT_ONLY: nothing uploaded)."""
+        state_init the entries are output only (SSW_ALIGN_STATE_OUT_ONLY: nothing uploaded;
+        `out`, if given, is the int32 [n,3] array they are written to, whatever it held)."""
         n_ph = plan.total_phones
         tmatid = np.ascontiguousarray(tmatid, np.int16)
         assert len(tmatid) == n_ph
         sf = np.zeros(n_ph, np.int32) if sf is None else np.ascontiguousarray(sf, np.int32)
         ef = (np.full(n_ph, INT_MAX, np.int32) if ef is None
               else np.ascontiguousarray(ef, np.int32))
-        states = (np.empty((n_ph * 3, 3), np.int32) if state_init is None
-                  else np.ascontiguousarray(state_init, np.int32).copy())
+        if state_init is not None:
+            states = np.ascontiguousarray(state_init, np.int32).copy()
+        elif out is not None:
+            assert out.dtype == np.int32 and out.shape == (n_ph * 3, 3) and out.flags.c_contiguous
+            states = out
+        else:
+            states = np.empty((n_ph * 3, 3), np.int32)
         status = np.zeros(plan.n_utts, np.int32)
         _check(self._L.ssw_align_batch_compact(self._m, plan._p, _ptr(d_compact), _ptr(tmatid),
                                                _ptr(sf), _ptr(ef), _ptr(states), _ptr(status),

@@ -62,3 +62,28 @@ def test_no_line_from_rank_zero_is_an_error(monkeypatch, capsys):
     with pytest.raises(SystemExit) as e:
         bench.self_launch(2)
     assert "no line" in str(e.value)
+
+
+def test_an_early_death_does_not_wait_for_rank_zero(monkeypatch, capsys):
+    """rank 1 dies at once while rank 0 sits in a rendezvous that will never
+    complete (here: a sleep of ten minutes).  The parent must notice the dead rank within
+    moments, stop rank 0 and fail -- not block in rank 0's pipe until a process-group timeout."""
+    import time
+
+    def script(r):
+        if r == 1:
+            return "import sys; sys.exit(3)"
+        return "import time; print('waiting', flush=True); time.sleep(600)"
+    _patched_popen(monkeypatch, script)
+    t0 = time.time()
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(2)
+    assert time.time() - t0 < 30
+    assert "code 3" in str(e.value)
+
+
+def test_a_hung_job_ends_at_the_parents_limit(monkeypatch, capsys):
+    monkeypatch.setenv("SSW_BENCH_LAUNCH_TIMEOUT", "1")
+    _patched_popen(monkeypatch, lambda r: "import time; time.sleep(600)")
+    with pytest.raises(SystemExit):
+        bench.self_launch(2)

@@ -57,7 +57,9 @@ def _both_ways(gpu, feats, frame_off, phone_off, senid, tmat, sf=None, ef=None,
         gpu.score_batch_compact(d_feats, plan, d_c, scorer=scorer)
         gpu._L.ssw_device_synchronize()
         rows = _compact_rows(gpu, plan, d_c, frame_off, phone_off)
-        st_c, status_c = gpu.align_batch_compact(plan, d_c, tmat, sf, ef)
+        # output only (SSW_ALIGN_STATE_OUT_ONLY): whatever the array held must not matter
+        junk = np.full((len(tmat) * 3, 3), 0x5a5a5a5a, np.int32)
+        st_c, status_c = gpu.align_batch_compact(plan, d_c, tmat, sf, ef, out=junk)
     finally:
         for p in (d_feats, d_full, d_c):
             gpu.device_free(p)
@@ -120,6 +122,88 @@ def test_every_alignment_kernel_reads_compact_rows(gpu_en, orc_en, means_en, mon
     monkeypatch.setenv("SSW_ALIGN_KERNEL", kernel)
     got = _both_ways(gpu_en, feats, frame_off, phone_off, senid, tmat, sf, ef)
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+
+
+def test_output_only_entries_survive_a_hand_on_to_the_full_token_kernel(gpu_en, orc_en, means_en):
+    """with SSW_ALIGN_STATE_OUT_ONLY (the default of align_batch_compact, of config 5
+    and of bench.py's config 3) a batch of which the byte-token kernel hands some utterances on is
+    run twice -- and the second run used to clear the device's entries and copy ALL of them back,
+    zeros for every utterance the first run had aligned, status 0.  Windows that end a phone
+    while its predecessor lives on (tests/test_gpu_align.py::test_byte_token_kernel_hands_on...)
+    make the hand-on happen; the entries must equal the full-row in / out call's, which that
+    test compares with the oracle."""
+    rng = np.random.default_rng(123)
+    n_utts = 24
+    phones = rng.integers(4, 140, size=n_utts).tolist()
+    lens = [int(p * rng.integers(3, 6) + 6) for p in phones]
+    feats, frame_off, phone_off, senid, tmat = _task(gpu_en, orc_en, means_en, lens, phones, 2100)
+    sf, ef = [], []
+    for p, f in zip(phones, lens):
+        mid_ = (np.arange(p) * f) // p
+        a = np.maximum(mid_ - 8, 0).astype(np.int32)
+        b = np.minimum(mid_ + f // p + 10, f).astype(np.int32)
+        b[1::3] = np.maximum(a[1::3] + 2, mid_[1::3] - 2)
+        b[-1] = f
+        sf.append(a)
+        ef.append(b)
+    sf, ef = np.concatenate(sf), np.concatenate(ef)
+    before = gpu_en.align_stats()
+    st, status = _both_ways(gpu_en, feats, frame_off, phone_off, senid, tmat, sf, ef)
+    after = gpu_en.align_stats()
+    assert after[1] - before[1] >= 2, "the windows were meant to make the byte-token kernel hand on"
+    ok = status == 0
+    assert 4 <= ok.sum(), status
+    for u in np.flatnonzero(ok):              # aligned utterances tile their frames
+        s = st[phone_off[u] * 3:phone_off[u + 1] * 3]
+        assert s[0, 0] == 0 and s[:, 1].sum() == lens[u], u
+    # against the oracle, from compact-call entries alone
+    d_feats = gpu_en.to_device(feats)
+    d_full = gpu_en.device_malloc(len(feats) * gpu_en.n_sen * 2)
+    try:
+        gpu_en.score_batch_device(d_feats, len(feats), frame_off, d_full)
+        full = np.zeros((len(feats), gpu_en.n_sen), np.int16)
+        gpu_en._L.ssw_device_synchronize()
+        gpu_en._L.ssw_memcpy_d2h(full.ctypes.data, d_full, full.nbytes)
+    finally:
+        gpu_en.device_free(d_feats)
+        gpu_en.device_free(d_full)
+    for u in range(n_utts):
+        sl = slice(phone_off[u], phone_off[u + 1])
+        rv, rst, _ = orc_en.state_align(full[frame_off[u]:frame_off[u + 1]], senid[sl], tmat[sl],
+                                        sf=sf[sl], ef=ef[sl])
+        assert (status[u] == 0) == (rv == 0), u
+        if rv == 0:
+            assert np.array_equal(st[phone_off[u] * 3:phone_off[u + 1] * 3], rst), u
+
+
+def test_output_only_entries_survive_a_fall_back_one_level_down(gpu_en, orc_en, means_en,
+                                                                 monkeypatch):
+    """The other rerun: an utterance that outgrows the sliding-window kernel (-(1 << 30)) is run
+    again a level down; with output-only entries the rerun starts from zeros, like the first run,
+    and the utterances the first run aligned keep their entries."""
+    shapes = [(300, 950), (300, 950), (5, 3), (192, 600), (40, 130), (192, 600), (8, 2)]
+    windowed = [True, False, False, False, False, True, False]
+    phones = [a for a, _ in shapes]
+    lens = [b for _, b in shapes]
+    feats, frame_off, phone_off, senid, tmat = _task(gpu_en, orc_en, means_en, lens, phones, 2300)
+    sf, ef = [], []
+    for (p, f), w in zip(shapes, windowed):
+        a = np.zeros(p, np.int32)
+        b = np.full(p, INT_MAX, np.int32)
+        if w:
+            mid = (np.arange(p) * f) // p
+            a = np.maximum(mid - 5, 0).astype(np.int32)
+            b = np.minimum(mid + f // p + 7, f).astype(np.int32)
+        sf.append(a)
+        ef.append(b)
+    sf, ef = np.concatenate(sf), np.concatenate(ef)
+    ref = _both_ways(gpu_en, feats, frame_off, phone_off, senid, tmat, sf, ef)
+    monkeypatch.setenv("SSW_ALIGN_KERNEL", "win")
+    monkeypatch.setenv("SSW_ALIGN_WIN_WAVES", "2")
+    got = _both_ways(gpu_en, feats, frame_off, phone_off, senid, tmat, sf, ef)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert (got[1] == 0).sum() >= 5 and (got[1] != 0).sum() >= 1
+    assert not (got[1] == -(1 << 30)).any()
 
 
 def test_golden_config3_through_compact_rows(gpu_en, orc_en, means_en):

@@ -391,6 +391,34 @@ def _ring_features(orc, means, total):
     return feats, off
 
 
+def test_host_call_cuts_long_utterances_and_hands_the_history_on(gpu_en, orc_en, means_en,
+                                                                 monkeypatch):
+    """ssw_score_batch_host used to size its pinned staging and device rows by the
+    longest utterance.  An utterance beyond SSW_HOST_PIPE_CAP frames (16,384; 300 here) is now
+    scored in pieces that carry the top-N history (carry_out -> carry_in), between short
+    utterances that are grouped as before: the rows must be those of the uncut utterances --
+    tie-heavy frames, so a piece that started from the reset history would differ -- and the
+    whole-call top-N view must cover every piece."""
+    feats = _tie_heavy_features(orc_en, means_en, 2500, 11)
+    off = np.array([0, 40, 1040, 1040, 1100, 1101, 2401, 2500], np.int32)   # 1000 and 1300 > cap
+    ref = np.concatenate([orc_en.ptm_score_utt(feats[off[u]:off[u + 1]])
+                          for u in range(len(off) - 1) if off[u + 1] > off[u]])
+    whole = gpu_en.score_batch(feats, off)
+    assert np.array_equal(whole, ref)
+    cw_whole, _ = gpu_en.last_topn(len(feats))
+    monkeypatch.setenv("SSW_HOST_PIPE_CAP", "300")
+    cut = gpu_en.score_batch(feats, off)
+    assert np.array_equal(cut, ref)
+    cw_cut, _ = gpu_en.last_topn(len(feats))
+    assert np.array_equal(cw_cut, cw_whole)
+    # the carried history matters on these inputs: the same pieces from the reset history differ
+    pieces_reset = np.concatenate([gpu_en.score_batch(feats[a:min(a + 300, 1040)])
+                                   for a in range(40, 1040, 300)])
+    assert not np.array_equal(pieces_reset, ref[40:1040])
+    monkeypatch.setenv("SSW_HOST_PIPE_CAP", "301")        # odd values are rounded down to even
+    assert np.array_equal(gpu_en.score_batch(feats, off), ref)
+
+
 def test_chain_over_utterances_follows_the_two_slot_ring(gpu_en, orc_en, means_en, monkeypatch):
     """the reference's history is a ring of two slots indexed by frame % 2 and frame
     numbers restart with every utterance (src/ptm_mgau.c:425-437, src/acmod.c:367), so frame 0
