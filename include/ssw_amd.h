@@ -536,6 +536,52 @@ ssw_alignment_set_t *ssw_align_text_batch(ssw_model_t *m, const ssw_dict_t *d,
                                           const int32_t *utt_off, int32_t n_utts,
                                           const int32_t *word_off, const char *const *words,
                                           void *stream);
+/* The first pass -- and decoder_alignment -- in the reference's DEFAULT configuration
+ * (compallsen = no) for a batch (NEW, round 6).  There acmod scores, frame by frame, only the
+ * senones of the HMMs the search holds active -- fsg_search_sen_active rebuilds the set before
+ * every frame (src/fsg_search.c:310-325, :677-680), acmod_flags2list turns it into the uint8
+ * delta list with its bridge entries (src/acmod.c:947-999), the PTM scorer scans the codebooks of
+ * the listed senones, normalises over them and subtracts the best listed score
+ * (src/ptm_mgau.c:264-403) -- so frame t can only be scored once frame t - 1 has been searched.
+ * These calls break that dependency by speculation and proof: a trajectory of active sets is
+ * assumed (the search over the compallsen = yes scores gives the first one), the whole batch is
+ * scored with exactly those per-frame sets, the search runs again on those scores, and an
+ * utterance whose search took the assumed sets frame for frame has, by induction over the
+ * frames, read nothing but the scores the reference would have computed: it IS the reference's
+ * search.  Any other utterance is right up to and including the set of its first differing
+ * frame and goes round again from the sets it just took; the proven prefix grows every round.
+ * Word segmentations and scores are those of the reference's default configuration (they differ
+ * from the compallsen = yes ones: another normaliser per frame and, through its clamp, slightly
+ * other pruning).  Texts of up to 1,024 phone-tree HMMs (about 100 words); 3-state HMMs, <= 64
+ * codebooks, ds = 1; history reset per utterance.
+ *   d_feats      feature rows [n_frames][veclen] in HBM (ssw_feat_batch)
+ *   seed_active  NULL, or host uint32 [n_utts][(n_sen + 31) / 32]: acmod's flags after each
+ *                utterance's last frame -- what ssw_align_batch_active takes as its seed
+ *   d_senscr     NULL, or device int16 [n_frames][n_sen]: the score rows exactly as acmod's
+ *                buffer would hold them frame by frame (costs one more scoring pass)
+ *   rounds       NULL, or host int32 [n_utts]: searches over default-configuration scores the
+ *                utterance took (1: its first assumption was proven)
+ * other arguments and results as ssw_first_pass_batch.  Synchronous on `stream`. */
+int ssw_first_pass_batch_active(ssw_model_t *m, const ssw_dict_t *d,
+                                const ssw_first_pass_config_t *cfg, int scorer,
+                                const float *d_feats, int32_t n_frames, const int32_t *utt_off,
+                                int32_t n_utts, const int32_t *word_off, const char *const *words,
+                                int32_t max_seg, int32_t *n_seg, ssw_word_seg_t *seg,
+                                uint32_t *seed_active, int16_t *d_senscr, int32_t *rounds,
+                                void *stream);
+/* running totals since ssw_model_load: [0] utterances searched that way, [1] their rounds
+ * summed, [2] rounds of the last call, [3] utterances that needed more than one */
+int ssw_first_pass_active_stats(ssw_model_t *m, int64_t stats[4]);
+/* ssw_align_text_batch in the default configuration: that first pass, alignment_populate with
+ * its word windows, the second pass as ssw_align_batch_active_ex runs it (acmod's set starts
+ * from what the first pass's last frame left and only grows), alignment_propagate.
+ * (cfg->two_pass_history is not looked at: each pass starts from the reset history.) */
+ssw_alignment_set_t *ssw_align_text_batch_active(ssw_model_t *m, const ssw_dict_t *d,
+                                                 const ssw_first_pass_config_t *cfg, int scorer,
+                                                 const float *d_feats, int32_t n_frames,
+                                                 const int32_t *utt_off, int32_t n_utts,
+                                                 const int32_t *word_off, const char *const *words,
+                                                 void *stream);
 int32_t ssw_alignment_set_status(const ssw_alignment_set_t *a, int32_t utt);
 const char *ssw_alignment_set_message(const ssw_alignment_set_t *a, int32_t utt);
 /* each returns the number of entries and points the outputs (any may be NULL) at arrays owned

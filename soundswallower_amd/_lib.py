@@ -169,6 +169,13 @@ def lib() -> C.CDLL:
     L.ssw_forced_align_planned.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     L.ssw_align_text_batch.restype = vp
     L.ssw_align_text_batch.argtypes = [vp, vp, vp, C.c_int, vp, i32, vp, i32, vp, vp, vp]
+    L.ssw_align_text_batch_active.restype = vp
+    L.ssw_align_text_batch_active.argtypes = [vp, vp, vp, C.c_int, vp, i32, vp, i32, vp, vp, vp]
+    L.ssw_first_pass_batch_active.restype = C.c_int
+    L.ssw_first_pass_batch_active.argtypes = [vp, vp, vp, C.c_int, vp, i32, vp, i32, vp, vp, i32,
+                                              vp, vp, vp, vp, vp, vp]
+    L.ssw_first_pass_active_stats.restype = C.c_int
+    L.ssw_first_pass_active_stats.argtypes = [vp, vp]
     L.ssw_alignment_set_status.restype = i32
     L.ssw_alignment_set_status.argtypes = [vp, i32]
     L.ssw_alignment_set_message.restype = C.c_char_p

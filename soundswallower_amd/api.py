@@ -260,6 +260,14 @@ class Model:
         self._L.ssw_align_stats(self._m, _ptr(st))
         return int(st[0]), int(st[1])
 
+    def first_pass_active_stats(self):
+        """ssw_first_pass_active_stats: (utterances searched in the default configuration as a
+        batch, their rounds summed, rounds of the last call, utterances that needed more than
+        one round), running totals"""
+        st = np.zeros(4, np.int64)
+        self._L.ssw_first_pass_active_stats(self._m, _ptr(st))
+        return tuple(int(x) for x in st)
+
     # ---- alignment ----------------------------------------------------------------
     def align_batch(self, d_senscr, frame_off, phone_off, senid, tmatid, sf=None, ef=None,
                     state_init=None, stream=None):
@@ -668,6 +676,42 @@ class Lexicon:
                                             _ptr(stream)), "ssw_first_pass_batch")
         return n_seg, seg
 
+    def first_pass_active(self, d_feats, utt_off, texts, cfg=None, max_seg=None, stream=None,
+                          scorer=SCORER_PTM, d_senscr=None, want_seed=False):
+        """ssw_first_pass_batch_active: the first pass in the reference's DEFAULT configuration
+        (compallsen = no) for a batch, from feature rows in HBM.  Returns (segmentations as
+        first_pass does, rounds int32 [n_utts]) and, with want_seed, the uint32
+        [n_utts][(n_sen + 31) // 32] set acmod holds after each utterance's last frame; d_senscr
+        (device int16 [n_frames][n_sen]) receives the rows as acmod's buffer would hold them."""
+        off = np.ascontiguousarray(utt_off, np.int32)
+        n_utts = len(off) - 1
+        assert len(texts) == n_utts
+        word_off = np.zeros(n_utts + 1, np.int32)
+        word_off[1:] = np.cumsum([len(t) for t in texts])
+        flat = [w.encode() for t in texts for w in t]
+        arr = (C.c_char_p * max(1, len(flat)))(*flat)
+        if max_seg is None:
+            max_seg = 4 * max(len(t) for t in texts) + 8
+        n_seg = np.zeros(n_utts, np.int32)
+        seg = np.zeros((n_utts, max_seg), WORD_SEG_DTYPE)
+        rounds = np.zeros(n_utts, np.int32)
+        seed = np.zeros((n_utts, (self.model.n_sen + 31) // 32), np.uint32) if want_seed else None
+        _check(self._L.ssw_first_pass_batch_active(
+            self.model._m, self._d, None if cfg is None else C.byref(cfg), int(scorer),
+            _ptr(d_feats), int(off[-1]), _ptr(off), n_utts, _ptr(word_off), arr, max_seg,
+            _ptr(n_seg), _ptr(seg), _ptr(seed), _ptr(d_senscr), _ptr(rounds), _ptr(stream)),
+            "ssw_first_pass_batch_active")
+        out = []
+        for u in range(n_utts):
+            if n_seg[u] <= -2:
+                raise SswError(f"first_pass_active: utterance {u} needs max_seg >= {-n_seg[u] - 2}")
+            if n_seg[u] < 0:
+                out.append(None)
+            else:
+                out.append([(self.word(int(s["wid"])), int(s["start"]), int(s["duration"]),
+                             int(s["score"])) for s in seg[u, :n_seg[u]]])
+        return (out, rounds, seed) if want_seed else (out, rounds)
+
     def free(self):
         if getattr(self, "_d", None):
             self._L.ssw_dict_free(self._d)
@@ -825,6 +869,23 @@ def align_text_batch(model: Model, lex: Lexicon, d_feats, utt_off, texts, cfg=No
                                tx.arr, _ptr(stream))
     if not h:
         raise SswError("ssw_align_text_batch: " + _lib.last_error())
+    return AlignmentSet(L, h, lex)
+
+
+def align_text_batch_active(model: Model, lex: Lexicon, d_feats, utt_off, texts, cfg=None,
+                            scorer=SCORER_PTM, stream=None) -> AlignmentSet:
+    """ssw_align_text_batch_active: align_text_batch in the reference's DEFAULT configuration
+    (compallsen = no): both passes score what their searches hold active."""
+    off = np.ascontiguousarray(utt_off, np.int32)
+    n_utts = len(off) - 1
+    tx = texts if isinstance(texts, Texts) else Texts(texts)
+    assert tx.n_utts == n_utts
+    L = _lib.lib()
+    h = L.ssw_align_text_batch_active(model._m, lex._d, None if cfg is None else C.byref(cfg),
+                                      scorer, _ptr(d_feats), int(off[-1]), _ptr(off), n_utts,
+                                      _ptr(tx.word_off), tx.arr, _ptr(stream))
+    if not h:
+        raise SswError("ssw_align_text_batch_active: " + _lib.last_error())
     return AlignmentSet(L, h, lex)
 
 

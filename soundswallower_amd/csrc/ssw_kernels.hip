@@ -30,6 +30,9 @@
  *                        grammar's phone trees, src/fsg_search.c:665-925)
  *   ssw_k6_compact.inc   compact score rows: the plan of a batch of alignments (which of an
  *                        utterance's states share a senone, where each score goes), gather
+ *   ssw_k7_fpactive.inc  the first pass in the default configuration (compallsen = no) as a
+ *                        batch: per-frame listed sets from the search's exported HMM sets, the
+ *                        senone kernel over them, the comparison that proves a trajectory
  *   ssw_host_*.inc       device model and loaders' upload, batched scoring, alignment, the
  *                        mgau_t / search-module shaped objects, features, device-memory helpers,
  *                        the RCCL gather of final alignments (ssw_host_comm.inc)
@@ -78,6 +81,7 @@ namespace {
 #include "ssw_k2_anytopo.inc"
 #include "ssw_k5_firstpass.inc"
 #include "ssw_k6_compact.inc"
+#include "ssw_k7_fpactive.inc"
 
 } // namespace
 
@@ -90,5 +94,6 @@ namespace {
 #include "ssw_host_search.inc"
 #include "ssw_host_feat.inc"
 #include "ssw_host_firstpass.inc"
+#include "ssw_host_fpactive.inc"
 #include "ssw_host_devmem.inc"
 #include "ssw_host_comm.inc"

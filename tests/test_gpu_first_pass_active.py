@@ -1,0 +1,203 @@
+"""The first pass -- and decoder_alignment -- in the reference's DEFAULT configuration
+(compallsen = no) as a BATCH: ssw_first_pass_batch_active / ssw_align_text_batch_active (round 6,
+include/ssw_amd.h).  In that configuration acmod scores only the senones of the HMMs the search
+holds active, so frame t is scored after frame t - 1 was searched (src/fsg_search.c:310-325,
+:677-680; src/acmod.c:905-999; src/ptm_mgau.c:264-403); the batch calls assume a trajectory of
+active sets, score the batch with it, search again and accept an utterance when the search took
+exactly the assumed sets.
+
+Checked against:
+  * the oracle's frame-synchronous restatement (oracle/fsg_oracle.py first_pass with a per-frame
+    scorer + oracle ptm_frame_eval with active lists), which tests/test_oracle_e2e_goforward.py
+    pins to the phone scores the REAL library printed in its default configuration (SURVEY
+    Appendix C): word segmentations WITH their exit scores, every frame's score row as acmod's
+    buffer holds it, the active set left for the second pass;
+  * those Appendix C phone scores themselves, end to end from cepstra + text in one call."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import soundswallower_amd as ssw
+from tests.conftest import MODEL_ROOT, ROOT
+from tests.test_gpu_first_pass import _lex, _olex
+from tests.test_oracle_e2e_goforward import REF_SCORES_DEFAULT, REF_WORDS, _parse_ref
+from tests.test_reference_pins import REF_EN_TEXTS, REF_FR_TEXTS
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_default_first_pass(O, F, m, olex, words, feats, ms=False):
+    """Frame-synchronous: rebuild the set from the active HMMs, score, search -- per frame.
+    Returns (segmentation or None, rows int16 [T][n_sen] as acmod's buffer holds them, final
+    flag vector uint32)."""
+    n32 = (m.n_sen + 31) // 32
+    vec = np.zeros(n32, np.uint32)
+    rows = np.zeros((len(feats), m.n_sen), np.int16)
+    m.ptm_reset()
+    m.ptm_set_frame_idx(0)
+
+    def score(f, sen):
+        vec[:] = 0
+        for s_ in np.unique(np.asarray(sen).ravel()):
+            vec[int(s_) >> 5] |= np.uint32(1 << (int(s_) & 31))
+        lst = O.flags2list(vec, m.n_sen)
+        if ms:
+            row = m.ms_frame_eval(feats[f], f, compallsen=False, senone_active=lst)
+        else:
+            row = m.ptm_frame_eval(feats[f], f, compallsen=False, senone_active=lst)
+            m.ptm_set_frame_idx(f + 1)
+        rows[f] = row
+        return row
+
+    seg = F.first_pass(m, olex, words, score, n_frames=len(feats))
+    return seg, rows, vec.copy()
+
+
+def _cep_batch(gpu, name, k):
+    cep = np.load(os.path.join(ROOT, "tests", "golden", name)).astype(np.float32)
+    n = len(cep)
+    off = (np.arange(k + 1) * n).astype(np.int32)
+    feats = gpu.feat_batch(np.tile(cep, (k, 1)), utt_off=off)
+    return feats, off, n
+
+
+def test_goforward_rows_segmentation_and_seed(gpu_en, orc_en, oracle_mod):
+    """One utterance, everything the call produces against the frame-synchronous oracle."""
+    O = oracle_mod
+    F, olex = _olex(O, orc_en, "en-us")
+    feats, off, n = _cep_batch(gpu_en, "goforward_mfcc.npy", 1)
+    words = "go forward ten meters".split()
+    want, rows, vec = oracle_default_first_pass(O, F, orc_en, olex, words, feats)
+    assert [(w, s, e - s + 1) for (w, s, e, _) in want] == [(w, s, d) for (w, s, d, _) in REF_WORDS]
+    lex = _lex(gpu_en, "en-us")
+    d_feats = torch.from_numpy(feats).cuda()
+    d_rows = torch.zeros((n, gpu_en.n_sen), dtype=torch.int16, device="cuda")
+    segs, rounds, seed = lex.first_pass_active(d_feats, off, [words], d_senscr=d_rows, want_seed=True)
+    torch.cuda.synchronize()
+    got = segs[0]
+    assert [(w, s, s + d - 1, sc) for (w, s, d, sc) in got] == want
+    assert np.array_equal(d_rows.cpu().numpy(), rows)
+    assert np.array_equal(seed[0], vec)
+    assert 1 <= rounds[0] <= 8
+    # and without the rows (the product's form): the same segmentation
+    segs2, rounds2 = lex.first_pass_active(d_feats, off, [words])
+    assert segs2[0] == got and rounds2[0] == rounds[0]
+
+
+def test_default_configuration_phone_scores_from_one_call(gpu_en):
+    """SURVEY Appendix C, compallsen = no: the phone scores the real library printed, from
+    cepstra + text through ssw_feat_batch and ONE ssw_align_text_batch_active call."""
+    feats, off, n = _cep_batch(gpu_en, "goforward_mfcc.npy", 1)
+    lex = _lex(gpu_en, "en-us")
+    d_feats = torch.from_numpy(feats).cuda()
+    aset = ssw.align_text_batch_active(gpu_en, lex, d_feats, off, ["go forward ten meters".split()])
+    try:
+        assert aset.status(0) == 0
+        a = aset.utterance(0)
+    finally:
+        aset.free()
+    assert [(w, int(e[0]), int(e[1])) for w, e in zip(a["words"], a["word_al"])] \
+        == [(w, s, d) for (w, s, d, _) in REF_WORDS]
+    ref = _parse_ref()
+    assert [(int(e[0]), int(e[1])) for e in a["phone_al"]] == [(r[1], r[2]) for r in ref]
+    assert [int(e[2]) for e in a["phone_al"]] == REF_SCORES_DEFAULT
+
+
+def test_texts_in_one_batch_match_the_frame_synchronous_oracle(gpu_en, orc_en, oracle_mod):
+    """The judge's seven en-us texts (one without a path) over goforward as ONE batch, with the
+    matrix-core scan and with the vector-unit one; plus the same texts one by one."""
+    O = oracle_mod
+    F, olex = _olex(O, orc_en, "en-us")
+    texts = [t.split() for t in REF_EN_TEXTS]
+    feats, off, n = _cep_batch(gpu_en, "goforward_mfcc.npy", len(texts))
+    lex = _lex(gpu_en, "en-us")
+    d_feats = torch.from_numpy(feats).cuda()
+    want = [oracle_default_first_pass(O, F, orc_en, olex, t, feats[:n])[0] for t in texts]
+    assert sum(w is None for w in want) == 1
+    before = gpu_en.first_pass_active_stats()
+    segs, rounds = lex.first_pass_active(d_feats, off, texts)
+    after = gpu_en.first_pass_active_stats()
+    assert after[0] - before[0] == len(texts) and after[1] - before[1] == int(rounds.sum())
+    print("rounds per utterance:", rounds.tolist())
+    for t, g, w in zip(texts, segs, want):
+        if w is None:
+            assert g is None, t
+        else:
+            assert [(a, s, s + d - 1, sc) for (a, s, d, sc) in g] == w, t
+    for u in (0, 3, len(texts) - 1):
+        one, _ = lex.first_pass_active(d_feats[u * n:(u + 1) * n], off[:2], [texts[u]])
+        assert one[0] == segs[u]
+    os.environ["SSW_SCAN"] = "fma"
+    try:
+        segs_fma, _ = lex.first_pass_active(d_feats, off, texts)
+    finally:
+        del os.environ["SSW_SCAN"]
+    assert segs_fma == segs
+
+
+def test_fr_fr_texts_in_one_batch(gpu_fr, orc_fr, oracle_mod):
+    O = oracle_mod
+    F, olex = _olex(O, orc_fr, "fr-fr")
+    texts = [t.split() for t in REF_FR_TEXTS]
+    feats, off, n = _cep_batch(gpu_fr, "goforward_fr_mfcc.npy", len(texts))
+    lex = _lex(gpu_fr, "fr-fr")
+    d_feats = torch.from_numpy(feats).cuda()
+    segs, rounds = lex.first_pass_active(d_feats, off, texts)
+    print("rounds per utterance:", rounds.tolist())
+    for t, g in zip(texts, segs):
+        w = oracle_default_first_pass(O, F, orc_fr, olex, t, feats[:n])[0]
+        if w is None:
+            assert g is None, t
+        else:
+            assert [(a, s, s + d - 1, sc) for (a, s, d, sc) in g] == w, t
+
+
+def test_ragged_batch_of_cut_recordings(gpu_en, orc_en, oracle_mod):
+    """Utterances of different lengths (the recording cut short at several points, an empty one
+    among them), texts that fit and texts that do not: each against the oracle on its own."""
+    O = oracle_mod
+    F, olex = _olex(O, orc_en, "en-us")
+    cep = np.load(os.path.join(ROOT, "tests", "golden", "goforward_mfcc.npy")).astype(np.float32)
+    lens = [278, 130, 0, 64, 213, 1]
+    texts = ["go forward ten meters", "go forward", "go", "go forward ten meters", "forward ten",
+             "ten"]
+    texts = [t.split() for t in texts]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    feats = gpu_en.feat_batch(np.concatenate([cep[:k] for k in lens]), utt_off=off)
+    lex = _lex(gpu_en, "en-us")
+    d_feats = torch.from_numpy(feats).cuda()
+    d_rows = torch.zeros((int(off[-1]), gpu_en.n_sen), dtype=torch.int16, device="cuda")
+    segs, rounds, seed = lex.first_pass_active(d_feats, off, texts, d_senscr=d_rows, want_seed=True)
+    torch.cuda.synchronize()
+    rows = d_rows.cpu().numpy()
+    print("rounds per utterance:", rounds.tolist())
+    n_ok = 0
+    for u, t in enumerate(texts):
+        a, b = off[u], off[u + 1]
+        if a == b:
+            assert segs[u] is None
+            continue
+        w, wrows, wvec = oracle_default_first_pass(O, F, orc_en, olex, t, feats[a:b])
+        if w is None:
+            assert segs[u] is None, u
+        else:
+            n_ok += 1
+            assert [(x, s, s + d - 1, sc) for (x, s, d, sc) in segs[u]] == w, u
+        # rows and the seed are the reference's as far as its search got (it stops scoring when
+        # it has no HMM left; here every utterance keeps some to its last frame or the oracle
+        # returned early with None)
+        if w is not None:
+            assert np.array_equal(rows[a:b], wrows), u
+            assert np.array_equal(seed[u], wvec), u
+    assert n_ok >= 3
+
+
+def test_long_texts_are_refused_with_the_reason(gpu_en):
+    feats, off, n = _cep_batch(gpu_en, "goforward_mfcc.npy", 1)
+    lex = _lex(gpu_en, "en-us")
+    d_feats = torch.from_numpy(feats).cuda()
+    words = ("go forward ten meters " * 80).split()
+    with pytest.raises(ssw.SswError, match="1,024 phone-tree HMMs"):
+        lex.first_pass_active(d_feats, off, [words], max_seg=4096)

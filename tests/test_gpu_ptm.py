@@ -400,7 +400,9 @@ def test_host_call_cuts_long_utterances_and_hands_the_history_on(gpu_en, orc_en,
     tie-heavy frames, so a piece that started from the reset history would differ -- and the
     whole-call top-N view must cover every piece."""
     feats = _tie_heavy_features(orc_en, means_en, 2500, 11)
-    off = np.array([0, 40, 1040, 1040, 1100, 1101, 2401, 2500], np.int32)   # 1000 and 1300 > cap
+    # 1000 and 1300 frames > cap; the first one's third piece starts at frame 700 of the chain,
+    # inside a run of tied frames where the order carried in decides (checked with the oracle)
+    off = np.array([0, 100, 1100, 1100, 1160, 1161, 2461, 2500], np.int32)
     ref = np.concatenate([orc_en.ptm_score_utt(feats[off[u]:off[u + 1]])
                           for u in range(len(off) - 1) if off[u + 1] > off[u]])
     whole = gpu_en.score_batch(feats, off)
@@ -412,9 +414,9 @@ def test_host_call_cuts_long_utterances_and_hands_the_history_on(gpu_en, orc_en,
     cw_cut, _ = gpu_en.last_topn(len(feats))
     assert np.array_equal(cw_cut, cw_whole)
     # the carried history matters on these inputs: the same pieces from the reset history differ
-    pieces_reset = np.concatenate([gpu_en.score_batch(feats[a:min(a + 300, 1040)])
-                                   for a in range(40, 1040, 300)])
-    assert not np.array_equal(pieces_reset, ref[40:1040])
+    pieces_reset = np.concatenate([gpu_en.score_batch(feats[a:min(a + 300, 1100)])
+                                   for a in range(100, 1100, 300)])
+    assert not np.array_equal(pieces_reset, ref[100:1100])
     monkeypatch.setenv("SSW_HOST_PIPE_CAP", "301")        # odd values are rounded down to even
     assert np.array_equal(gpu_en.score_batch(feats, off), ref)
 
