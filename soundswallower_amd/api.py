@@ -683,26 +683,10 @@ class Lexicon:
         first_pass does, rounds int32 [n_utts]) and, with want_seed, the uint32
         [n_utts][(n_sen + 31) // 32] set acmod holds after each utterance's last frame; d_senscr
         (device int16 [n_frames][n_sen]) receives the rows as acmod's buffer would hold them."""
-        off = np.ascontiguousarray(utt_off, np.int32)
-        n_utts = len(off) - 1
-        assert len(texts) == n_utts
-        word_off = np.zeros(n_utts + 1, np.int32)
-        word_off[1:] = np.cumsum([len(t) for t in texts])
-        flat = [w.encode() for t in texts for w in t]
-        arr = (C.c_char_p * max(1, len(flat)))(*flat)
-        if max_seg is None:
-            max_seg = 4 * max(len(t) for t in texts) + 8
-        n_seg = np.zeros(n_utts, np.int32)
-        seg = np.zeros((n_utts, max_seg), WORD_SEG_DTYPE)
-        rounds = np.zeros(n_utts, np.int32)
-        seed = np.zeros((n_utts, (self.model.n_sen + 31) // 32), np.uint32) if want_seed else None
-        _check(self._L.ssw_first_pass_batch_active(
-            self.model._m, self._d, None if cfg is None else C.byref(cfg), int(scorer),
-            _ptr(d_feats), int(off[-1]), _ptr(off), n_utts, _ptr(word_off), arr, max_seg,
-            _ptr(n_seg), _ptr(seg), _ptr(seed), _ptr(d_senscr), _ptr(rounds), _ptr(stream)),
-            "ssw_first_pass_batch_active")
+        n_seg, seg, rounds, seed = self.first_pass_active_raw(d_feats, utt_off, texts, cfg, max_seg,
+                                                              stream, scorer, d_senscr, want_seed)
         out = []
-        for u in range(n_utts):
+        for u in range(len(n_seg)):
             if n_seg[u] <= -2:
                 raise SswError(f"first_pass_active: utterance {u} needs max_seg >= {-n_seg[u] - 2}")
             if n_seg[u] < 0:
@@ -711,6 +695,27 @@ class Lexicon:
                 out.append([(self.word(int(s["wid"])), int(s["start"]), int(s["duration"]),
                              int(s["score"])) for s in seg[u, :n_seg[u]]])
         return (out, rounds, seed) if want_seed else (out, rounds)
+
+    def first_pass_active_raw(self, d_feats, utt_off, texts, cfg=None, max_seg=None, stream=None,
+                              scorer=SCORER_PTM, d_senscr=None, want_seed=False):
+        """The C call alone: (n_seg, seg WORD_SEG_DTYPE [n_utts][max_seg], rounds, seed or None);
+        texts: list of word lists, or a Texts."""
+        off = np.ascontiguousarray(utt_off, np.int32)
+        n_utts = len(off) - 1
+        tx = texts if isinstance(texts, Texts) else Texts(texts)
+        assert tx.n_utts == n_utts
+        if max_seg is None:
+            max_seg = 4 * tx.max_words + 8
+        n_seg = np.zeros(n_utts, np.int32)
+        seg = np.zeros((n_utts, max_seg), WORD_SEG_DTYPE)
+        rounds = np.zeros(n_utts, np.int32)
+        seed = np.zeros((n_utts, (self.model.n_sen + 31) // 32), np.uint32) if want_seed else None
+        _check(self._L.ssw_first_pass_batch_active(
+            self.model._m, self._d, None if cfg is None else C.byref(cfg), int(scorer),
+            _ptr(d_feats), int(off[-1]), _ptr(off), n_utts, _ptr(tx.word_off), tx.arr, max_seg,
+            _ptr(n_seg), _ptr(seg), _ptr(seed), _ptr(d_senscr), _ptr(rounds), _ptr(stream)),
+            "ssw_first_pass_batch_active")
+        return n_seg, seg, rounds, seed
 
     def free(self):
         if getattr(self, "_d", None):

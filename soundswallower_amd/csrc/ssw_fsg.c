@@ -839,6 +839,10 @@ ssw_fp_graphs_build(const ssw_model_t *m, const ssw_dict_t *d, const ssw_first_p
         ssw_fp_graphs_free(g);
         return NULL;
     }
+    {
+        static uint64_t next_uid = 0; /* (graphs of several host threads: atomically) */
+        g->uid = __atomic_add_fetch(&next_uid, 1, __ATOMIC_RELAXED);
+    }
     return g;
 }
 

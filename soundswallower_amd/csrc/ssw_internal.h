@@ -130,6 +130,7 @@ typedef struct ssw_fp_graphs_s {
     int32_t n_tw;
     int32_t *tw, *tw_off, *twin_ref, *tw_rk;
     int32_t beam, pbeam, wbeam;
+    uint64_t uid; /* unique per built set of graphs (never 0): the device copy's cache key */
 } ssw_fp_graphs_t;
 ssw_fp_graphs_t *ssw_fp_graphs_build(const ssw_model_t *m, const struct ssw_dict_s *d,
                                      const ssw_first_pass_config_t *cfg, int32_t n_utts,

@@ -212,6 +212,87 @@ def soak_first_pass(a):
                       "differences": 0, "label_differences_among_identical_alternates": n_label}))
 
 
+def soak_fp_active(a):
+    """The DEFAULT configuration's first pass as a batch (ssw_first_pass_batch_active: speculation
+    and proof) against the frame-synchronous oracle: random texts of 1-8 words, synthetic FEATURES
+    that follow one path through the text's phone trees at random noise levels (clean to nearly
+    lost), audio cut short, texts that do not fit, ragged batches, either scan; every other batch
+    also compares every score row as acmod's buffer holds it and the set left for the second
+    pass.  Words, frames and exit scores -- or the same failure."""
+    import torch
+    from oracle import fsg_oracle as F
+    from soundswallower_amd.synth import read_raw_means
+    from tests.test_gpu_first_pass_active import oracle_default_first_pass
+    from tools.bench_first_pass import path_through
+    mdir = ssw.model_dir(a.model)
+    m = ssw.Model(mdir)
+    orc = O.Model(mdir)
+    lex = ssw.Lexicon(m, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
+    olex = F.Lexicon(orc, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
+    vocab = [w for w in olex.order[:olex.filler_start] if "(" not in w]
+    means = read_raw_means(mdir)
+    mixw = m.table("ptm_mixw").reshape(m.n_feat, m.n_density, m.n_sen)
+    sen2cb = m.table("sen2cb")
+    best_d = mixw.argmin(axis=1)
+    sen_mean = np.concatenate([means[sen2cb, f, best_d[f]] for f in range(m.n_feat)], axis=1)
+    rng = np.random.default_rng(909 + a.seed)
+    t_end = time.time() + a.seconds
+    n_utts = n_frames = n_fail = n_batches = n_rows = 0
+    rounds_hist = {}
+    while time.time() < t_end:
+        os.environ.pop("SSW_SCAN", None)
+        if n_batches % 4 == 3:
+            os.environ["SSW_SCAN"] = "fma"
+        nb = int(rng.integers(1, 9))
+        texts, feats = [], []
+        for _ in range(nb):
+            words = [vocab[int(rng.integers(len(vocab)))] for _ in range(int(rng.integers(1, 9)))]
+            nodes, _ = lex.first_pass_graph(words)
+            path = path_through(lex, nodes, len(words), rng)
+            states = np.array([s_ for i in path for s_ in nodes[i]["senid"]])
+            per = rng.integers(1, 5, size=len(states))
+            sen = np.repeat(states, per)
+            noise = float(rng.choice([0.2, 0.5, 1.0, 2.0]))
+            x = sen_mean[sen] + rng.standard_normal((len(sen), sen_mean.shape[1])).astype(np.float32) * noise
+            if rng.random() < 0.15:                       # audio cut short
+                x = x[:max(1, int(len(x) * rng.uniform(0.3, 0.95)))]
+            if rng.random() < 0.1:                        # another text
+                words = [vocab[int(rng.integers(len(vocab)))] for _ in range(len(words))]
+            texts.append(words)
+            feats.append(x.astype(np.float32))
+        off = np.concatenate([[0], np.cumsum([len(x) for x in feats])]).astype(np.int32)
+        allf = np.ascontiguousarray(np.concatenate(feats), np.float32)
+        d_feats = torch.from_numpy(allf).cuda()
+        want_rows = n_batches % 2 == 0
+        d_rows = (torch.zeros((len(allf), m.n_sen), dtype=torch.int16, device="cuda")
+                  if want_rows else None)
+        got, rounds, seed = lex.first_pass_active(d_feats, off, texts, d_senscr=d_rows, want_seed=True)
+        torch.cuda.synchronize()
+        rows = d_rows.cpu().numpy() if want_rows else None
+        for u, (t, x, g) in enumerate(zip(texts, feats, got)):
+            want, wrows, wvec = oracle_default_first_pass(O, F, orc, olex, t, x)
+            rounds_hist[int(rounds[u])] = rounds_hist.get(int(rounds[u]), 0) + 1
+            if want is None:
+                assert g is None, ("GPU found a path the oracle does not", t)
+                n_fail += 1
+            else:
+                assert g is not None, ("GPU lost the path", t)
+                mine = [(w, s_, s_ + dd - 1, sc) for (w, s_, dd, sc) in g]
+                assert [y[1:] for y in mine] == [y[1:] for y in want], (t, mine, want)
+                assert np.array_equal(seed[u], wvec), ("seed", t)
+                if want_rows:
+                    assert np.array_equal(rows[off[u]:off[u + 1]], wrows), ("rows", t)
+                    n_rows += len(x)
+            n_utts += 1
+            n_frames += len(x)
+        n_batches += 1
+    print(json.dumps({"mode": "fp_active", "model": a.model, "batches": n_batches,
+                      "utterances": n_utts, "frames": n_frames, "without_a_path": n_fail,
+                      "score_rows_compared": n_rows,
+                      "rounds_histogram": {str(k): v for k, v in sorted(rounds_hist.items())},
+                      "differences": 0}))
+
+
 def soak_text(a):
     """decoder_alignment end to end: ssw_forced_align_batch (first pass, populate, constrained
     state alignment, propagate) against the oracle's pipeline -- restated first pass, then
@@ -320,13 +401,15 @@ def main():
     ap.add_argument("--model", default="en-us")
     ap.add_argument("--seed", type=int, default=0,
                     help="added to the mode's own seed: another run, other inputs")
-    ap.add_argument("--mode", default="ptm", choices=["ptm", "ms", "align", "topo", "first_pass", "text"])
+    ap.add_argument("--mode", default="ptm", choices=["ptm", "ms", "align", "topo", "first_pass", "text", "fp_active"])
     ap.add_argument("--max-len", type=int, default=400,
                     help="ptm / ms: utterances of up to this many frames, 1-5 per batch (the "
                          "matrix-core scan takes batches from ~2100 frames: use 1600)")
     a = ap.parse_args()
     if a.mode == "first_pass":
         return soak_first_pass(a)
+    if a.mode == "fp_active":
+        return soak_fp_active(a)
     if a.mode == "text":
         return soak_text(a)
     if a.mode == "topo":

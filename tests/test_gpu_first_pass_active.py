@@ -201,3 +201,54 @@ def test_long_texts_are_refused_with_the_reason(gpu_en):
     words = ("go forward ten meters " * 80).split()
     with pytest.raises(ssw.SswError, match="1,024 phone-tree HMMs"):
         lex.first_pass_active(d_feats, off, [words], max_seg=4096)
+
+
+def test_ms_scorer(oracle_mod, orc_fr, tmp_path):
+    """The same through the ms scorer (src/ms_mgau.c:322-365: only the listed senones are
+    evaluated and written, best of them subtracted with the clamp; no codebook bookkeeping, no
+    history): fr-fr with synthesised mixture_weights, the French recording with three texts."""
+    O = oracle_mod
+    from oracle import fsg_oracle as F
+    from tests.test_cabi_host import synth_mixw_from_sendump
+    src = os.path.join(MODEL_ROOT, "fr-fr")
+    mixw = str(tmp_path / "mixture_weights")
+    synth_mixw_from_sendump(orc_fr, mixw)
+    kw = dict(mdef=os.path.join(src, "mdef"), means=os.path.join(src, "means"),
+              tmat=os.path.join(src, "transition_matrices"), mixw=mixw)
+    g = ssw.Model(variances=os.path.join(src, "variances"), **kw)
+    o = O.Model(vars=os.path.join(src, "variances"), **kw)
+    olex = F.Lexicon(o, os.path.join(src, "dict.txt"), os.path.join(src, "noisedict.txt"))
+    lex = ssw.Lexicon(g, os.path.join(src, "dict.txt"), os.path.join(src, "noisedict.txt"))
+    texts = [t.split() for t in list(REF_FR_TEXTS)[:3]]
+    feats, off, n = _cep_batch(g, "goforward_fr_mfcc.npy", len(texts))
+    d_feats = torch.from_numpy(feats).cuda()
+    d_rows = torch.zeros((len(feats), g.n_sen), dtype=torch.int16, device="cuda")
+    segs, rounds = lex.first_pass_active(d_feats, off, texts, scorer=ssw.SCORER_MS, d_senscr=d_rows)
+    torch.cuda.synchronize()
+    rows = d_rows.cpu().numpy()
+    print("rounds per utterance:", rounds.tolist())
+    n_ok = 0
+    for u, t in enumerate(texts):
+        listed = []
+
+        class Spy:                                   # which entries each frame lists
+            pass
+        real = O.flags2list
+
+        def spy(vec, n_sen):
+            lst = real(vec, n_sen)
+            listed.append(np.cumsum(np.asarray(lst, np.int64)))
+            return lst
+        O.flags2list = spy
+        try:
+            w, wrows, _ = oracle_default_first_pass(O, F, o, olex, t, feats[:n], ms=True)
+        finally:
+            O.flags2list = real
+        if w is None:
+            assert segs[u] is None, t
+            continue
+        n_ok += 1
+        assert [(x, s, s + d - 1, sc) for (x, s, d, sc) in segs[u]] == w, t
+        for f, ids in enumerate(listed):
+            assert np.array_equal(rows[off[u] + f, ids], wrows[f, ids]), (t, f)
+    assert n_ok >= 2
