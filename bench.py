@@ -20,7 +20,7 @@ Prints ONE JSON line on rank 0, including
                  dealt over the N ranks, each rank scoring and force-aligning its shard, ONE
                  gather of the final alignments over RCCL; job utterance-frames/s, align RTF,
                  gather_ms and a CRC of the gathered alignments that does not depend on N;
-  `batch_16384`, `batch_65536`, `real_features`, `align`, `text_align`  (N = 1 only) the same scoring step
+  `batch_16384`, `batch_65536`, `real_features`, `align`, `text_align`, `text_align_default_config`  (N = 1 only) the same scoring step
                  at 65,536 frames, on features of a real recording, and BASELINE configs[2]
                  from phone strings and from text;
   `config4`      (N = 1 only) BASELINE configs[3]: the ms scorer on fr-fr, 8192 frames per step.
@@ -623,6 +623,15 @@ def main():
             out["align_default_config"] = bench_align_active.run(model)
         except Exception as e:      # noqa: BLE001 -- the headline line must still come out
             out["align_default_config"] = {"error": str(e)}
+        # and the whole of decoder_alignment from text in that configuration (round 6): the first
+        # pass by speculation and proof (ssw_first_pass_batch_active), then the second pass over
+        # the growing active set -- tools/bench_first_pass_active.py, text_align's workload
+        import bench_first_pass_active
+        try:
+            out["text_align_default_config"] = bench_first_pass_active.run(ssw, model, lex, torch,
+                                                                           reps=2)
+        except Exception as e:      # noqa: BLE001
+            out["text_align_default_config"] = {"error": str(e)}
     if world == 1 and not args.no_extra:
         # BASELINE configs[3]: the ms scorer (ms_gauden + ms_senone kernels), fr-fr, 8192 frames
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))

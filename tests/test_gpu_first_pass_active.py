@@ -231,9 +231,7 @@ def test_ms_scorer(oracle_mod, orc_fr, tmp_path):
     for u, t in enumerate(texts):
         listed = []
 
-        class Spy:                                   # which entries each frame lists
-            pass
-        real = O.flags2list
+        real = O.flags2list                          # spy: which entries each frame lists
 
         def spy(vec, n_sen):
             lst = real(vec, n_sen)
