@@ -135,6 +135,16 @@ def test_texts_in_one_batch_match_the_frame_synchronous_oracle(gpu_en, orc_en, o
     finally:
         del os.environ["SSW_SCAN"]
     assert segs_fma == segs
+    # the rounds over the unproven utterances one by one (what large batches do once few are
+    # left: their unlisted entries refreshed from their compallsen = yes scores), and never
+    for sub in ("1", "0"):
+        os.environ["SSW_FPA_SUB"] = sub
+        try:
+            segs_sub, rounds_sub = lex.first_pass_active(d_feats, off, texts)
+        finally:
+            del os.environ["SSW_FPA_SUB"]
+        assert segs_sub == segs, sub
+        print("SSW_FPA_SUB=%s rounds per utterance:" % sub, rounds_sub.tolist())
 
 
 def test_fr_fr_texts_in_one_batch(gpu_fr, orc_fr, oracle_mod):
