@@ -47,7 +47,7 @@ VALU_PEAK_TOPS = 78.6          # vector fp32 peak with an FMA counted once (SURV
 # mul, sub): 864,864 for en-us PTM
 N_SIMD = 1024                   # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9
-PMC_FILE = "r05_pmc.json"      # rocprofv3 --pmc passes of this step (tools/pmc_pass.py); only
+PMC_FILE = "r06_pmc.json"      # rocprofv3 --pmc passes of this step (tools/pmc_pass.py); only
                                # quoted when its kernel_src_sha equals this tree's
 
 

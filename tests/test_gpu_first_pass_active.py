@@ -105,6 +105,53 @@ def test_default_configuration_phone_scores_from_one_call(gpu_en):
     assert [int(e[2]) for e in a["phone_al"]] == REF_SCORES_DEFAULT
 
 
+def test_decoder_alignment_of_a_batch_of_texts(gpu_en, oracle_mod):
+    """ssw_align_text_batch_active over the judge's seven en-us texts as one batch against the
+    oracle's two restated searches around its per-frame scorer with active lists (the pipeline
+    tests/test_oracle_e2e_goforward.py pins to the real library's default-configuration phone
+    scores): every word and every phone's start, duration and score.  The batch call starts
+    each pass from the reset history (include/ssw_amd.h); so does the oracle here."""
+    from tests.test_oracle_e2e_goforward import default_configuration_alignment
+    O = oracle_mod
+    m = O.Model(os.path.join(MODEL_ROOT, "en-us"))
+    texts = list(REF_EN_TEXTS)
+    feats, off, n = _cep_batch(gpu_en, "goforward_mfcc.npy", len(texts))
+    lex = _lex(gpu_en, "en-us")
+    d_feats = torch.from_numpy(feats).cuda()
+    aset = ssw.align_text_batch_active(gpu_en, lex, d_feats, off, [t.split() for t in texts])
+    n_ok = 0
+    try:
+        for u, t in enumerate(texts):
+            m.ptm_reset()
+            m.ptm_set_frame_idx(0)
+
+            def eval_frame(f, feat, lst):
+                row = m.ptm_frame_eval(feat, f, compallsen=False, senone_active=lst)
+                m.ptm_set_frame_idx(f + 1)
+                return row
+
+            def rewind():
+                m.ptm_reset()
+                m.ptm_set_frame_idx(0)
+
+            seg, ph_start, ph_dur, ph_score = default_configuration_alignment(
+                O, m, feats[:n], eval_frame, rewind, text=t)
+            if seg is None:
+                assert aset.status(u) == 1, t
+                continue
+            assert aset.status(u) == 0, t
+            a = aset.utterance(u)
+            n_ok += 1
+            assert [(w, int(e[0]), int(e[1])) for w, e in zip(a["words"], a["word_al"])] \
+                == [(w, s, e - s + 1) for (w, s, e, _) in seg], t
+            assert [int(e[0]) for e in a["phone_al"]] == [int(x) for x in ph_start], t
+            assert [int(e[1]) for e in a["phone_al"]] == [int(x) for x in ph_dur], t
+            assert [int(e[2]) for e in a["phone_al"]] == [int(x) for x in ph_score], t
+    finally:
+        aset.free()
+    assert n_ok == 6
+
+
 def test_texts_in_one_batch_match_the_frame_synchronous_oracle(gpu_en, orc_en, oracle_mod):
     """The judge's seven en-us texts (one without a path) over goforward as ONE batch, with the
     matrix-core scan and with the vector-unit one; plus the same texts one by one."""

@@ -176,7 +176,8 @@ REF_SCORES_DEFAULT = [-67, -49, -56, -100, -47, -54, -43, -59, -35, -207, -53, -
                       -136, -67, -141, -379]
 
 
-def default_configuration_alignment(O, m, feats, eval_frame, rewind):
+def default_configuration_alignment(O, m, feats, eval_frame, rewind,
+                                    text="go forward ten meters"):
     """The reference's default is compallsen=no: acmod scores only the senones of the active
     HMMs, through the uint8 delta list of acmod_flags2list (src/acmod.c:947-999), and the scorer
     normalises over that set.  The first pass clears and rebuilds the set every frame
@@ -207,7 +208,9 @@ def default_configuration_alignment(O, m, feats, eval_frame, rewind):
         set_bits(sen)
         return score(f)
 
-    seg = F.first_pass(m, lex, "go forward ten meters".split(), first_pass_scores, n_frames=T)
+    seg = F.first_pass(m, lex, text.split(), first_pass_scores, n_frames=T)
+    if seg is None:
+        return None, None, None, None
     # ---- second pass (decoder_alignment): rewind, constrained windows, growing active set
     words = [(w, s, e - s + 1) for (w, s, e, _) in seg]
     phones = populate(O, m, words)

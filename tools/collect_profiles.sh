@@ -1,10 +1,10 @@
 #!/bin/bash
 # Everything the round's profiles/ files come from, in one call ON the GPU box:
-#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r05'
+#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r06'
 # Writes gpurun_out/<tag>/; copy what is to be judged into profiles/<tag>_* afterwards
 # (tools/collect_profiles.sh does not touch profiles/).  rocprofv3 gets `python3 <script>` directly
 # after `--` (no shell, no env in between) and --pmc passes are never combined with other traces.
-tag=${1:-r05}
+tag=${1:-r06}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
@@ -30,6 +30,8 @@ prof config5_align python3 $R/tools/bench_align.py --utts 2048 --reps 2
 prof align_active python3 $R/tools/bench_align_active.py --reps 2
 prof first_pass python3 $R/tools/bench_first_pass.py --reps 5
 prof page python3 $R/tools/bench_page.py
+# round 6: the default configuration from text as a batch (speculation and proof)
+prof fpa python3 $R/tools/bench_first_pass_active.py --reps 3
 cd $R
 timeout 900 python3 tools/pmc_pass.py $tag > $O/pmc.log 2>&1
 tail -2 $O/pmc.log
@@ -43,6 +45,8 @@ SSW_JOB_ROWS=full SSW_ALIGN_BT=0 timeout 300 python tools/bench_align.py --utts 
 timeout 300 python tools/bench_align_active.py > $O/align_active.json 2>/dev/null
 timeout 300 python tools/bench_align_active.py --ms > $O/align_active_ms.json 2>/dev/null
 timeout 300 python tools/bench_host_boundary.py > $O/host_boundary.json 2>/dev/null
+SSW_ALIGN_TIMING=1 timeout 300 python tools/bench_first_pass_active.py --reps 3 > $O/fpa_synth.json 2> $O/fpa_synth_rounds.txt
+timeout 300 python tools/bench_first_pass_active.py --real --utts 240 > $O/fpa_real.json 2>/dev/null
 # texts of ~300 words (2,940 phone-tree HMMs): the sliding-window kernel, which texts beyond 1,024
 # HMMs take since round 5 (the register instances with 2 and 4 HMMs per thread, the ones with
 # scratch, lost to it from ~1,200 HMMs up and were removed: VERDICT r4 weak 7); the second line
@@ -53,7 +57,8 @@ SSW_FP_KERNEL=big timeout 300 python tools/bench_first_pass.py --utts 32 --words
 timeout 900 python3 tools/pmc_cmd.py gpurun_out/$tag/align_pmc_2048.json 'viterbi_align\w+|ptm_senone_kernel|ptm_topn_mfma_kernel' -- python3 tools/bench_align.py --utts 2048 --reps 1 > $O/align_pmc_2048.log 2>&1
 timeout 900 python3 tools/pmc_cmd.py gpurun_out/$tag/align_pmc_256.json 'viterbi_align\w+' -- python3 tools/bench_align.py --utts 256 --reps 1 > $O/align_pmc_256.log 2>&1
 timeout 900 python3 tools/pmc_cmd.py gpurun_out/$tag/align_active_pmc.json 'senone_active2_kernel|viterbi_align\w+' -- python3 tools/bench_align_active.py --reps 1 > $O/align_active_pmc.log 2>&1
+timeout 900 python3 tools/pmc_cmd.py gpurun_out/$tag/fpa_pmc.json 'senone_listed_kernel|fpa_plan_kernel|fpa_compare_kernel|first_pass_kernel|ptm_topn_mfma_kernel' -- python3 tools/bench_first_pass_active.py --reps 1 > $O/fpa_pmc.log 2>&1
 # the senone kernel's selectable shapes on the headline workload
 timeout 600 bash tools/bench_sen_shapes.sh $tag > $O/sen_shapes.log 2>&1
-rm -rf $R/gpurun_out/pmc_align_pmc_2048 $R/gpurun_out/pmc_align_pmc_256 $R/gpurun_out/pmc_align_active_pmc
+rm -rf $R/gpurun_out/pmc_align_pmc_2048 $R/gpurun_out/pmc_align_pmc_256 $R/gpurun_out/pmc_align_active_pmc $R/gpurun_out/pmc_fpa_pmc
 ls $O
