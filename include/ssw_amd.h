@@ -552,8 +552,9 @@ ssw_alignment_set_t *ssw_align_text_batch(ssw_model_t *m, const ssw_dict_t *d,
  * frame and goes round again from the sets it just took; the proven prefix grows every round.
  * Word segmentations and scores are those of the reference's default configuration (they differ
  * from the compallsen = yes ones: another normaliser per frame and, through its clamp, slightly
- * other pruning).  Texts of up to 1,024 phone-tree HMMs (about 100 words); 3-state HMMs, <= 64
- * codebooks, ds = 1; history reset per utterance.
+ * other pruning).  Texts of any length (beyond 1,024 phone-tree HMMs the long-text search
+ * kernels export their sets, as ssw_first_pass_batch uses them); 3-state HMMs, <= 64 codebooks,
+ * ds = 1; history reset per utterance.
  *   d_feats      feature rows [n_frames][veclen] in HBM (ssw_feat_batch)
  *   seed_active  NULL, or host uint32 [n_utts][(n_sen + 31) / 32]: acmod's flags after each
  *                utterance's last frame -- what ssw_align_batch_active takes as its seed

@@ -218,7 +218,8 @@ def soak_fp_active(a):
     that follow one path through the text's phone trees at random noise levels (clean to nearly
     lost), audio cut short, texts that do not fit, ragged batches, either scan; every other batch
     also compares every score row as acmod's buffer holds it and the set left for the second
-    pass.  Words, frames and exit scores -- or the same failure."""
+    pass; every tenth batch with a text of 110-150 words (the long-text search kernels).  Words,
+    frames and exit scores -- or the same failure."""
     import torch
     from oracle import fsg_oracle as F
     from soundswallower_amd.synth import read_raw_means
@@ -237,7 +238,7 @@ def soak_fp_active(a):
     sen_mean = np.concatenate([means[sen2cb, f, best_d[f]] for f in range(m.n_feat)], axis=1)
     rng = np.random.default_rng(909 + a.seed)
     t_end = time.time() + a.seconds
-    n_utts = n_frames = n_fail = n_batches = n_rows = 0
+    n_utts = n_frames = n_fail = n_batches = n_rows = n_long = 0
     rounds_hist = {}
     while time.time() < t_end:
         os.environ.pop("SSW_SCAN", None)
@@ -245,8 +246,15 @@ def soak_fp_active(a):
             os.environ["SSW_SCAN"] = "fma"
         nb = int(rng.integers(1, 9))
         texts, feats = [], []
-        for _ in range(nb):
-            words = [vocab[int(rng.integers(len(vocab)))] for _ in range(int(rng.integers(1, 9)))]
+        # every tenth batch holds a text beyond 1,024 phone-tree HMMs: the whole batch then goes
+        # through the long-text search kernels (sliding window; every twentieth: HBM-resident)
+        long_one = n_batches % 10 == 9
+        os.environ.pop("SSW_FP_WIN", None)
+        if n_batches % 20 == 19:
+            os.environ["SSW_FP_WIN"] = "0"
+        for k_ in range(nb):
+            n_w = int(rng.integers(110, 150)) if long_one and k_ == 0 else int(rng.integers(1, 9))
+            words = [vocab[int(rng.integers(len(vocab)))] for _ in range(n_w)]
             nodes, _ = lex.first_pass_graph(words)
             path = path_through(lex, nodes, len(words), rng)
             states = np.array([s_ for i in path for s_ in nodes[i]["senid"]])
@@ -266,7 +274,9 @@ def soak_fp_active(a):
         want_rows = n_batches % 2 == 0
         d_rows = (torch.zeros((len(allf), m.n_sen), dtype=torch.int16, device="cuda")
                   if want_rows else None)
-        got, rounds, seed = lex.first_pass_active(d_feats, off, texts, d_senscr=d_rows, want_seed=True)
+        got, rounds, seed = lex.first_pass_active(d_feats, off, texts, d_senscr=d_rows, want_seed=True,
+                                                  max_seg=2048 if long_one else None)
+        n_long += 1 if long_one else 0
         torch.cuda.synchronize()
         rows = d_rows.cpu().numpy() if want_rows else None
         for u, (t, x, g) in enumerate(zip(texts, feats, got)):
@@ -288,7 +298,7 @@ def soak_fp_active(a):
         n_batches += 1
     print(json.dumps({"mode": "fp_active", "model": a.model, "batches": n_batches,
                       "utterances": n_utts, "frames": n_frames, "without_a_path": n_fail,
-                      "score_rows_compared": n_rows,
+                      "score_rows_compared": n_rows, "batches_with_a_long_text": n_long,
                       "rounds_histogram": {str(k): v for k, v in sorted(rounds_hist.items())},
                       "differences": 0}))
 

@@ -251,13 +251,36 @@ def test_ragged_batch_of_cut_recordings(gpu_en, orc_en, oracle_mod):
     assert n_ok >= 3
 
 
-def test_long_texts_are_refused_with_the_reason(gpu_en):
-    feats, off, n = _cep_batch(gpu_en, "goforward_mfcc.npy", 1)
+@pytest.mark.timeout(900)
+def test_long_texts_take_the_long_text_kernels(gpu_en, orc_en, oracle_mod, monkeypatch):
+    """Texts beyond 1,024 phone-tree HMMs: the sliding-window search kernel (and, forced, the
+    HBM-resident one) export their active sets as well -- only the words of a frame's row that
+    hold an active HMM, the rows cleared beforehand.  Two texts of 130 words with synthetic audio
+    that follows them and a short one in the same batch, against the frame-synchronous oracle."""
+    from tools.bench_first_pass import build_workload
+    O = oracle_mod
+    F, olex = _olex(O, orc_en, "en-us")
     lex = _lex(gpu_en, "en-us")
+    texts, feats, nodes = build_workload(ssw, gpu_en, lex, 2, 2600, 130, noise=0.4, seed=77)
+    assert nodes > 1024
+    short_t, short_f, _ = build_workload(ssw, gpu_en, lex, 1, 300, 4, noise=0.4, seed=78)
+    texts = texts + short_t
+    feats = np.concatenate([feats, short_f])
+    off = np.array([0, 2600, 5200, 5500], np.int32)
     d_feats = torch.from_numpy(feats).cuda()
-    words = ("go forward ten meters " * 80).split()
-    with pytest.raises(ssw.SswError, match="1,024 phone-tree HMMs"):
-        lex.first_pass_active(d_feats, off, [words], max_seg=4096)
+    want = [oracle_default_first_pass(O, F, orc_en, olex, t, feats[off[u]:off[u + 1]])
+            for u, t in enumerate(texts)]
+    assert all(w[0] is not None for w in want)
+    for knobs in ({}, {"SSW_FP_WIN": "0"}, {"SSW_FP_WIN": "0", "SSW_FP_BAND": "0"}):
+        for k, v in knobs.items():
+            monkeypatch.setenv(k, v)
+        segs, rounds, seed = lex.first_pass_active(d_feats, off, texts, max_seg=2048, want_seed=True)
+        for k in knobs:
+            monkeypatch.delenv(k)
+        print(knobs, "rounds per utterance:", rounds.tolist())
+        for u, (g, (w, _, wvec)) in enumerate(zip(segs, want)):
+            assert [(a, s, s + d - 1, sc) for (a, s, d, sc) in g] == w, (knobs, u)
+            assert np.array_equal(seed[u], wvec), (knobs, u)
 
 
 def test_ms_scorer(oracle_mod, orc_fr, tmp_path):
