@@ -144,11 +144,23 @@ gpu_text_alignment(decoder_t *d, ssw_dict_t *gpu_dict, const char *const *words,
     int i, n;
 
     if (d_feat == NULL || d_scr == NULL
-        || ssw_memcpy_h2d(d_feat, acmod->feat_buf[0][0], feat_bytes) < 0
-        || ssw_score_batch(gpu_model, SSW_SCORER_PTM, d_feat, n_frames, utt_off, 1, d_scr, NULL) < 0
-        || ssw_device_synchronize() < 0
-        || (set = ssw_forced_align_batch(gpu_model, gpu_dict, NULL, d_scr, n_frames, utt_off, 1,
-                                         word_off, words, NULL)) == NULL) {
+        || ssw_memcpy_h2d(d_feat, acmod->feat_buf[0][0], feat_bytes) < 0) {
+        E_ERROR("%s\n", ssw_last_error());
+        goto done;
+    }
+    if (!acmod->compallsen) {
+        /* the reference's default: acmod scores what the searches hold active (src/acmod.c:905-999).
+         * Both passes in that configuration, one call (round 6: the first pass by speculation
+         * and proof, include/ssw_amd.h) -- the scores decoder_alignment reports are then the
+         * ones this decoder would have computed frame by frame */
+        set = ssw_align_text_batch_active(gpu_model, gpu_dict, NULL, SSW_SCORER_PTM, d_feat, n_frames,
+                                          utt_off, 1, word_off, words, NULL);
+    } else if (ssw_score_batch(gpu_model, SSW_SCORER_PTM, d_feat, n_frames, utt_off, 1, d_scr, NULL) == 0
+               && ssw_device_synchronize() == 0) {
+        set = ssw_forced_align_batch(gpu_model, gpu_dict, NULL, d_scr, n_frames, utt_off, 1,
+                                     word_off, words, NULL);
+    }
+    if (set == NULL) {
         E_ERROR("%s\n", ssw_last_error());
         goto done;
     }

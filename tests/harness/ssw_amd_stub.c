@@ -120,6 +120,11 @@ ssw_forced_align_batch(ssw_model_t *m, const ssw_dict_t *d, const ssw_first_pass
                        const int16_t *d_senscr, int32_t n_frames, const int32_t *utt_off,
                        int32_t n_utts, const int32_t *word_off, const char *const *words, void *stream)
 { (void)m; (void)d; (void)cfg; (void)d_senscr; (void)n_frames; (void)utt_off; (void)n_utts; (void)word_off; (void)words; (void)stream; return NULL; }
+ssw_alignment_set_t *
+ssw_align_text_batch_active(ssw_model_t *m, const ssw_dict_t *d, const ssw_first_pass_config_t *cfg,
+                            int scorer, const float *d_feats, int32_t n_frames, const int32_t *utt_off,
+                            int32_t n_utts, const int32_t *word_off, const char *const *words, void *stream)
+{ (void)m; (void)d; (void)cfg; (void)scorer; (void)d_feats; (void)n_frames; (void)utt_off; (void)n_utts; (void)word_off; (void)words; (void)stream; return NULL; }
 int32_t ssw_alignment_set_status(const ssw_alignment_set_t *a, int32_t utt) { (void)a; (void)utt; return 1; }
 int32_t ssw_alignment_set_words(const ssw_alignment_set_t *a, int32_t utt, const int32_t **wid,
                                 const ssw_align_entry_t **al) { (void)a; (void)utt; (void)wid; (void)al; return 0; }
