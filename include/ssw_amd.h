@@ -562,7 +562,11 @@ ssw_alignment_set_t *ssw_align_text_batch(ssw_model_t *m, const ssw_dict_t *d,
  *                buffer would hold them frame by frame (costs one more scoring pass)
  *   rounds       NULL, or host int32 [n_utts]: searches over default-configuration scores the
  *                utterance took (1: its first assumption was proven)
- * other arguments and results as ssw_first_pass_batch.  Synchronous on `stream`. */
+ * other arguments and results as ssw_first_pass_batch.  Synchronous on `stream`.
+ * Device memory the model keeps for these calls (grow-only, freed with the model): two tables
+ * of exported sets (8 bytes per 64 phone-tree HMMs and frame), a bitmap of listed senones per
+ * frame (n_sen / 8 bytes), the longest utterance's score rows once more, and -- when d_senscr
+ * is NULL -- the batch's score rows [n_frames][n_sen] (shared with ssw_align_text_batch). */
 int ssw_first_pass_batch_active(ssw_model_t *m, const ssw_dict_t *d,
                                 const ssw_first_pass_config_t *cfg, int scorer,
                                 const float *d_feats, int32_t n_frames, const int32_t *utt_off,
