@@ -296,3 +296,37 @@ def test_default_configuration_scores(oracle_mod):
     ref = _parse_ref()
     assert [(int(a), int(b)) for a, b in zip(ph_start, ph_dur)] == [(r[1], r[2]) for r in ref]
     assert [int(x) for x in ph_score] == REF_SCORES_DEFAULT
+
+
+@pytest.mark.parametrize("text", ["go ten meters forward", "hello world", "ten"])
+def test_default_configuration_history_across_the_rewind(oracle_mod, text):
+    """decoder_alignment's second pass starts from the top-N history the first pass left
+    (acmod_rewind keeps it, src/decoder.c:786-793); ssw_align_text_batch_active starts each pass
+    from the reset history (include/ssw_amd.h).  On the reference's recording the two agree for
+    every text tried -- a carried order only matters where truncated densities tie, and the
+    default configuration scores a few hundred senones a frame, not 5126 -- which is what this
+    pins: words, phone boundaries and phone scores, carried against reset."""
+    O = oracle_mod
+    m = O.Model(os.path.join(MODEL_ROOT, "en-us"))
+    feats = goforward_features(O)
+
+    def run(carry):
+        m.ptm_reset()
+        m.ptm_set_frame_idx(0)
+
+        def eval_frame(f, feat, lst):
+            row = m.ptm_frame_eval(feat, f, compallsen=False, senone_active=lst)
+            m.ptm_set_frame_idx(f + 1)
+            return row
+
+        def rewind():
+            if not carry:
+                m.ptm_reset()
+            m.ptm_set_frame_idx(0)
+
+        return default_configuration_alignment(O, m, feats, eval_frame, rewind, text=text)
+
+    a, b = run(True), run(False)
+    assert a[0] is not None and a[0] == b[0]
+    for x, y in zip(a[1:], b[1:]):
+        assert np.array_equal(x, y)
