@@ -39,8 +39,8 @@ def _parse_ref():
     return out
 
 
-def _pronunciations(words):
-    d = os.path.join(MODEL_ROOT, "en-us")
+def _pronunciations(words, model="en-us"):
+    d = os.path.join(MODEL_ROOT, model)
     want = set(words)
     pron = {}
     for fn in ("dict.txt", "noisedict.txt"):
@@ -52,10 +52,10 @@ def _pronunciations(words):
     return pron
 
 
-def populate(O, m, words):
+def populate(O, m, words, model="en-us"):
     """alignment_populate (src/ps_alignment.c:132-247): words [(name, start, dur)] -> per phone
     (ciname, ssid, tmat, word index)."""
-    pron = _pronunciations([w[0] for w in words])
+    pron = _pronunciations([w[0] for w in words], model)
     ci = lambda n: O.ciphone_id(m, n)
     sil = ci("SIL")
     ssid_of, tmat_of = m.phone_ssid, m.phone_tmat
@@ -177,7 +177,7 @@ REF_SCORES_DEFAULT = [-67, -49, -56, -100, -47, -54, -43, -59, -35, -207, -53, -
 
 
 def default_configuration_alignment(O, m, feats, eval_frame, rewind,
-                                    text="go forward ten meters"):
+                                    text="go forward ten meters", model="en-us"):
     """The reference's default is compallsen=no: acmod scores only the senones of the active
     HMMs, through the uint8 delta list of acmod_flags2list (src/acmod.c:947-999), and the scorer
     normalises over that set.  The first pass clears and rebuilds the set every frame
@@ -189,7 +189,7 @@ def default_configuration_alignment(O, m, feats, eval_frame, rewind,
     acmod_rewind.  Returns (first-pass segmentation, phone start, duration, score)."""
     import ctypes as C
     from oracle import fsg_oracle as F
-    d = os.path.join(MODEL_ROOT, "en-us")
+    d = os.path.join(MODEL_ROOT, model)
     lex = F.Lexicon(m, os.path.join(d, "dict.txt"), os.path.join(d, "noisedict.txt"))
     T = len(feats)
     n_words32 = (m.n_sen + 31) // 32
@@ -213,7 +213,7 @@ def default_configuration_alignment(O, m, feats, eval_frame, rewind,
         return None, None, None, None
     # ---- second pass (decoder_alignment): rewind, constrained windows, growing active set
     words = [(w, s, e - s + 1) for (w, s, e, _) in seg]
-    phones = populate(O, m, words)
+    phones = populate(O, m, words, model)
     n = len(phones)
     senid = np.ascontiguousarray(m.sseq[[p[1] for p in phones]], np.uint16)
     tmat = np.array([p[2] for p in phones], np.int16)
@@ -298,7 +298,8 @@ def test_default_configuration_scores(oracle_mod):
     assert [int(x) for x in ph_score] == REF_SCORES_DEFAULT
 
 
-@pytest.mark.parametrize("text", ["go ten meters forward", "hello world", "ten"])
+@pytest.mark.parametrize("text", ["go ten meters forward", "hello world", "ten",
+                                  "fr:dix mètres avance de"])
 def test_default_configuration_history_across_the_rewind(oracle_mod, text):
     """decoder_alignment's second pass starts from the top-N history the first pass left
     (acmod_rewind keeps it, src/decoder.c:786-793); ssw_align_text_batch_active starts each pass
@@ -307,8 +308,14 @@ def test_default_configuration_history_across_the_rewind(oracle_mod, text):
     default configuration scores a few hundred senones a frame, not 5126 -- which is what this
     pins: words, phone boundaries and phone scores, carried against reset."""
     O = oracle_mod
-    m = O.Model(os.path.join(MODEL_ROOT, "en-us"))
-    feats = goforward_features(O)
+    model = "fr-fr" if text.startswith("fr:") else "en-us"
+    text = text[3:] if text.startswith("fr:") else text
+    m = O.Model(os.path.join(MODEL_ROOT, model))
+    if model == "fr-fr":
+        from tests.test_first_pass_oracle import features
+        feats = features(O, "goforward_fr.raw")
+    else:
+        feats = goforward_features(O)
 
     def run(carry):
         m.ptm_reset()
@@ -324,7 +331,8 @@ def test_default_configuration_history_across_the_rewind(oracle_mod, text):
                 m.ptm_reset()
             m.ptm_set_frame_idx(0)
 
-        return default_configuration_alignment(O, m, feats, eval_frame, rewind, text=text)
+        return default_configuration_alignment(O, m, feats, eval_frame, rewind, text=text,
+                                               model=model)
 
     a, b = run(True), run(False)
     assert a[0] is not None and a[0] == b[0]
