@@ -580,13 +580,21 @@ int ssw_first_pass_active_stats(ssw_model_t *m, int64_t stats[4]);
 /* ssw_align_text_batch in the default configuration: that first pass, alignment_populate with
  * its word windows, the second pass as ssw_align_batch_active_ex runs it (acmod's set starts
  * from what the first pass's last frame left and only grows), alignment_propagate.
- * (cfg->two_pass_history is not looked at: each pass starts from the reset history.) */
+ * cfg->two_pass_history (PTM scorer): the second pass of every utterance starts, as
+ * decoder_alignment's does after acmod_rewind, from the top-N history its own first pass left
+ * in slot 1 -- every codebook's list after the last odd-numbered frame, the codebooks that
+ * frame did not scan included; 0 (default): from the reset history.  The two differ only
+ * where truncated densities tie; on the reference's recordings they do not (tests). */
 ssw_alignment_set_t *ssw_align_text_batch_active(ssw_model_t *m, const ssw_dict_t *d,
                                                  const ssw_first_pass_config_t *cfg, int scorer,
                                                  const float *d_feats, int32_t n_frames,
                                                  const int32_t *utt_off, int32_t n_utts,
                                                  const int32_t *word_off, const char *const *words,
                                                  void *stream);
+/* Debug / parity view: the top-N orders the last ssw_align_text_batch_active call with
+ * two_pass_history handed from every utterance's first pass to its second: host uint32
+ * [n_utts][n_cb * n_feat], 4 codewords packed best first. */
+int ssw_first_pass_active_carry(ssw_model_t *m, int32_t n_utts, uint32_t *rows);
 int32_t ssw_alignment_set_status(const ssw_alignment_set_t *a, int32_t utt);
 const char *ssw_alignment_set_message(const ssw_alignment_set_t *a, int32_t utt);
 /* each returns the number of entries and points the outputs (any may be NULL) at arrays owned

@@ -174,6 +174,8 @@ def lib() -> C.CDLL:
     L.ssw_first_pass_batch_active.restype = C.c_int
     L.ssw_first_pass_batch_active.argtypes = [vp, vp, vp, C.c_int, vp, i32, vp, i32, vp, vp, i32,
                                               vp, vp, vp, vp, vp, vp]
+    L.ssw_first_pass_active_carry.restype = C.c_int
+    L.ssw_first_pass_active_carry.argtypes = [vp, i32, vp]
     L.ssw_first_pass_active_stats.restype = C.c_int
     L.ssw_first_pass_active_stats.argtypes = [vp, vp]
     L.ssw_alignment_set_status.restype = i32

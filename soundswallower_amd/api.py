@@ -268,6 +268,14 @@ class Model:
         self._L.ssw_first_pass_active_stats(self._m, _ptr(st))
         return tuple(int(x) for x in st)
 
+    def first_pass_active_carry(self, n_utts):
+        """ssw_first_pass_active_carry: uint8 [n_utts][n_cb][n_feat][4] codewords, best first --
+        what the last align_text_batch_active call with two_pass_history handed on."""
+        rows = np.zeros((n_utts, self.n_cb * self.n_feat), np.uint32)
+        _check(self._L.ssw_first_pass_active_carry(self._m, n_utts, _ptr(rows)),
+               "ssw_first_pass_active_carry")
+        return rows.view(np.uint8).reshape(n_utts, self.n_cb, self.n_feat, 4)
+
     # ---- alignment ----------------------------------------------------------------
     def align_batch(self, d_senscr, frame_off, phone_off, senid, tmatid, sf=None, ef=None,
                     state_init=None, stream=None):

@@ -157,6 +157,71 @@ def test_decoder_alignment_of_a_batch_of_texts(gpu_en, gpu_fr, oracle_mod, name)
     assert n_ok == (6 if name == "en-us" else 5)
 
 
+@pytest.mark.parametrize("name", ["en-us", "fr-fr"])
+def test_two_pass_history_hands_on_what_the_first_pass_left(gpu_en, gpu_fr, oracle_mod, name):
+    """cfg.two_pass_history in the default configuration: decoder_alignment's second pass starts
+    from history slot 1 as the first pass left it (src/decoder.c:786-793, src/ptm_mgau.c:425-437)
+    -- every codebook's list after the last odd-numbered frame, including the codebooks that
+    frame did not scan (re-sorted by every frame since they were last scanned).  The orders the
+    batch call hands on (fpa_carry_rows_kernel: derived from the features and the proven
+    per-frame codebook masks) against the oracle's scorer state after its frame-synchronous
+    first pass, all codebooks x streams; utterances cut to odd and even lengths; and the
+    alignments against the oracle pipeline that carries the history across the rewind."""
+    from tests.test_oracle_e2e_goforward import default_configuration_alignment
+    O = oracle_mod
+    from oracle import fsg_oracle as F
+    gpu = gpu_en if name == "en-us" else gpu_fr
+    d = os.path.join(MODEL_ROOT, name)
+    m = O.Model(d)
+    olex = F.Lexicon(m, os.path.join(d, "dict.txt"), os.path.join(d, "noisedict.txt"))
+    cep = np.load(os.path.join(ROOT, "tests", "golden", "goforward_mfcc.npy" if name == "en-us"
+                               else "goforward_fr_mfcc.npy")).astype(np.float32)
+    n = len(cep)
+    texts = (["go forward ten meters", "go forward", "go forward ten meters", "ten"] if name == "en-us"
+             else ["avance de dix mètres", "avance", "dix mètres avance de", "de de de"])
+    lens = [n, n - 1, 131, 2]                       # even, odd, odd, two frames
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    feats = gpu.feat_batch(np.concatenate([cep[:k] for k in lens]), utt_off=off)
+    lex = _lex(gpu, name)
+    d_feats = torch.from_numpy(feats).cuda()
+    cfg = lex.first_pass_config(two_pass_history=1)
+    aset = ssw.align_text_batch_active(gpu, lex, d_feats, off, [t.split() for t in texts], cfg=cfg)
+    try:
+        rows = gpu.first_pass_active_carry(len(texts))
+        for u, t in enumerate(texts):
+            f_u = feats[off[u]:off[u + 1]]
+            m.ptm_reset()
+            m.ptm_set_frame_idx(0)
+
+            def eval_frame(f, feat, lst):
+                row = m.ptm_frame_eval(feat, f, compallsen=False, senone_active=lst)
+                m.ptm_set_frame_idx(f + 1)
+                return row
+
+            state = {}
+
+            def rewind():                            # the scorer's state as the first pass left it
+                T = len(f_u)
+                last_odd = ((T >> 1) << 1) - 1
+                state["cw"] = m.ptm_get_topn(last_odd)[0] if T >= 2 else None
+                m.ptm_set_frame_idx(0)
+
+            seg, ph_start, ph_dur, ph_score = default_configuration_alignment(
+                O, m, f_u, eval_frame, rewind, text=t, model=name)
+            if seg is None:
+                assert aset.status(u) == 1, t
+                continue
+            assert state["cw"] is not None
+            assert np.array_equal(rows[u].astype(np.int32), state["cw"]), (t, lens[u])
+            if aset.status(u) != 0:
+                continue
+            a = aset.utterance(u)
+            assert [int(e[0]) for e in a["phone_al"]] == [int(x) for x in ph_start], t
+            assert [int(e[2]) for e in a["phone_al"]] == [int(x) for x in ph_score], t
+    finally:
+        aset.free()
+
+
 def test_texts_in_one_batch_match_the_frame_synchronous_oracle(gpu_en, orc_en, oracle_mod):
     """The judge's seven en-us texts (one without a path) over goforward as ONE batch, with the
     matrix-core scan and with the vector-unit one; plus the same texts one by one."""
