@@ -303,6 +303,95 @@ def soak_fp_active(a):
                       "differences": 0}))
 
 
+def soak_text_active(a):
+    """decoder_alignment in the DEFAULT configuration as a batch (ssw_align_text_batch_active with
+    two_pass_history: the first pass by speculation and proof, populate, the second pass over the
+    growing active set from the history slot the first pass left) against the oracle's two
+    restated searches around its per-frame scorer with active lists
+    (tests/test_oracle_e2e_goforward.py: default_configuration_alignment, the pipeline pinned to
+    the real library's recorded default-configuration phone scores), history carried across the
+    rewind as the reference does: words, every phone's start, duration and score -- or the same
+    failure.  Random texts of 1-6 words, synthetic features that follow them."""
+    import torch
+    from oracle import fsg_oracle as F
+    from soundswallower_amd.synth import read_raw_means
+    from tests.test_oracle_e2e_goforward import default_configuration_alignment
+    from tools.bench_first_pass import path_through
+    mdir = ssw.model_dir(a.model)
+    m = ssw.Model(mdir)
+    orc = O.Model(mdir)
+    lex = ssw.Lexicon(m, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
+    olex = F.Lexicon(orc, os.path.join(mdir, "dict.txt"), os.path.join(mdir, "noisedict.txt"))
+    vocab = [w for w in olex.order[:olex.filler_start] if "(" not in w]
+    means = read_raw_means(mdir)
+    mixw = m.table("ptm_mixw").reshape(m.n_feat, m.n_density, m.n_sen)
+    sen2cb = m.table("sen2cb")
+    best_d = mixw.argmin(axis=1)
+    sen_mean = np.concatenate([means[sen2cb, f, best_d[f]] for f in range(m.n_feat)], axis=1)
+    rng = np.random.default_rng(4711 + a.seed)
+    cfg = lex.first_pass_config(two_pass_history=1)
+    t_end = time.time() + a.seconds
+    n_utts = n_frames = n_fail = n_batches = n_second_fail = 0
+    while time.time() < t_end:
+        nb = int(rng.integers(1, 7))
+        texts, feats = [], []
+        for _ in range(nb):
+            words = [vocab[int(rng.integers(len(vocab)))] for _ in range(int(rng.integers(1, 7)))]
+            nodes, _ = lex.first_pass_graph(words)
+            path = path_through(lex, nodes, len(words), rng)
+            states = np.array([s_ for i in path for s_ in nodes[i]["senid"]])
+            sen = np.repeat(states, rng.integers(1, 5, size=len(states)))
+            noise = float(rng.choice([0.2, 0.5, 1.0]))
+            x = sen_mean[sen] + rng.standard_normal((len(sen), sen_mean.shape[1])).astype(np.float32) * noise
+            if rng.random() < 0.1:
+                x = x[:max(2, int(len(x) * rng.uniform(0.4, 0.95)))]
+            texts.append(words)
+            feats.append(x.astype(np.float32))
+        off = np.concatenate([[0], np.cumsum([len(x) for x in feats])]).astype(np.int32)
+        d_feats = torch.from_numpy(np.ascontiguousarray(np.concatenate(feats), np.float32)).cuda()
+        aset = ssw.align_text_batch_active(m, lex, d_feats, off, texts, cfg=cfg)
+        try:
+            for u, (t, x) in enumerate(zip(texts, feats)):
+                orc.ptm_reset()
+                orc.ptm_set_frame_idx(0)
+
+                def eval_frame(f, feat, lst):
+                    row = orc.ptm_frame_eval(feat, f, compallsen=False, senone_active=lst)
+                    orc.ptm_set_frame_idx(f + 1)
+                    return row
+
+                try:
+                    seg, ph_start, ph_dur, ph_score = default_configuration_alignment(
+                        O, orc, x, eval_frame, lambda: orc.ptm_set_frame_idx(0), text=" ".join(t),
+                        model=a.model)
+                    second_ok = True
+                except AssertionError:          # the restated second pass found no final state
+                    seg, second_ok = "first pass only", False
+                n_utts += 1
+                n_frames += len(x)
+                if seg is None:
+                    assert aset.status(u) == 1, ("GPU aligned what the oracle's first pass lost", t)
+                    n_fail += 1
+                    continue
+                if not second_ok:
+                    assert aset.status(u) == 2, ("second pass", t, aset.status(u))
+                    n_second_fail += 1
+                    continue
+                assert aset.status(u) == 0, (t, aset.status(u))
+                al = aset.utterance(u)
+                assert [(w, int(e[0]), int(e[1])) for w, e in zip(al["words"], al["word_al"])] \
+                    == [(w, s_, e_ - s_ + 1) for (w, s_, e_, _) in seg], t
+                assert [int(e[0]) for e in al["phone_al"]] == [int(v) for v in ph_start], t
+                assert [int(e[1]) for e in al["phone_al"]] == [int(v) for v in ph_dur], t
+                assert [int(e[2]) for e in al["phone_al"]] == [int(v) for v in ph_score], t
+        finally:
+            aset.free()
+        n_batches += 1
+    print(json.dumps({"mode": "text_active", "model": a.model, "batches": n_batches,
+                      "utterances": n_utts, "frames": n_frames, "first_pass_without_a_path": n_fail,
+                      "second_pass_without_a_path": n_second_fail, "differences": 0}))
+
+
 def soak_text(a):
     """decoder_alignment end to end: ssw_forced_align_batch (first pass, populate, constrained
     state alignment, propagate) against the oracle's pipeline -- restated first pass, then
@@ -411,7 +500,7 @@ def main():
     ap.add_argument("--model", default="en-us")
     ap.add_argument("--seed", type=int, default=0,
                     help="added to the mode's own seed: another run, other inputs")
-    ap.add_argument("--mode", default="ptm", choices=["ptm", "ms", "align", "topo", "first_pass", "text", "fp_active"])
+    ap.add_argument("--mode", default="ptm", choices=["ptm", "ms", "align", "topo", "first_pass", "text", "fp_active", "text_active"])
     ap.add_argument("--max-len", type=int, default=400,
                     help="ptm / ms: utterances of up to this many frames, 1-5 per batch (the "
                          "matrix-core scan takes batches from ~2100 frames: use 1600)")
@@ -420,6 +509,8 @@ def main():
         return soak_first_pass(a)
     if a.mode == "fp_active":
         return soak_fp_active(a)
+    if a.mode == "text_active":
+        return soak_text_active(a)
     if a.mode == "text":
         return soak_text(a)
     if a.mode == "topo":

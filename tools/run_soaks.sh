@@ -21,6 +21,7 @@ python tests/soak_parity.py --seed $seed --mode first_pass --model fr-fr --secon
 python tests/soak_parity.py --seed $seed --mode text --seconds $secs > $O/${tag}_parity_soak_text.json 2> $O/${tag}_soak_text.err
 # round 6: the default configuration's first pass as a batch against the frame-synchronous oracle
 python tests/soak_parity.py --seed $seed --mode fp_active --seconds $secs > $O/${tag}_parity_soak_fp_active.json 2> $O/${tag}_soak_fp_active.err
+python tests/soak_parity.py --seed $seed --mode text_active --seconds $((secs / 2)) > $O/${tag}_parity_soak_text_active.json 2> $O/${tag}_soak_text_active.err
 SSW_FPA_SUB=1 python tests/soak_parity.py --seed $((seed + 100)) --mode fp_active --seconds $((secs / 2)) > $O/${tag}_parity_soak_fp_active_one_by_one.json 2> $O/${tag}_soak_fp_active_one_by_one.err
 tail -n 2 $O/${tag}_parity_soak_*.json
 tail -n 3 $O/${tag}_soak_*.err
